@@ -1,0 +1,391 @@
+// BM25 term-at-a-time scoring over term-major CSR postings with fp64 LDS accumulators and an
+// exact top-K.  gfx950 (MI355X) only.
+//
+// Replaces rank_bm25.BM25Okapi.get_scores + np.argsort behind BM25Indexer.search (reference
+// src/indexing/bm25_indexer.py:127-128).
+//
+// Layout in HBM: indptr[V+1] i64, rows[nnz] u32 (ascending inside a term), impact[nnz] f64,
+// idf[V] f64.  Algorithmic traffic per query: 12 bytes per posting of each query token.
+//
+// Kernel 1 (bm25_offsets_kernel): for every query token and every document tile, the position
+// of the tile's first posting inside the token's posting list (binary search).
+// Kernel 2 (bm25_tile_kernel): one workgroup per (document tile, query), tiles outermost in the
+// grid.  The tile's fp64 scores live in LDS; the query's tokens are applied one after the other
+// (a barrier in between), so each document's sum is formed in query-token order exactly like the
+// reference's `score += idf * impact` loop: bit-identical fp64 results.  The tile then emits its
+// candidates for the query's top-K: documents whose score reaches the query's shared threshold,
+// cut to the tile's K best; the K-th best of a tile raises the shared threshold (a lower bound
+// of the final K-th score), which prunes later tiles.
+// Kernel 3 (merge_topk_kernel): per query, the K best of all tiles' candidates, sorted.
+#include "common.h"
+#include "merge.h"
+
+namespace {
+
+constexpr int BM_NT = 256;
+constexpr int BM_TILE = 4096;      // documents per tile (32 KB of fp64 accumulators)
+
+struct Bm25Params {
+    const int64_t* indptr;
+    const uint32_t* rows;
+    const double* impact;
+    const double* idf;
+    int64_t n_docs;
+    const int32_t* qterms;
+    const int32_t* qoff;
+    int n_queries;
+    int n_terms_total;
+    uint32_t* toff;                // [n_terms_total][n_tiles + 1]
+    int n_tiles;
+    int k;
+    unsigned long long* tau;       // [n_queries] shared score-key threshold
+    uint64_t* cand_key;            // [n_queries][n_tiles][k]
+    uint32_t* cand_row;
+    int32_t* cand_count;           // [n_queries][n_tiles]
+    double* dense_out;             // scores mode: [n_docs]
+};
+
+__global__ void bm25_offsets_kernel(Bm25Params p) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = p.n_tiles + 1;
+    if (gid >= (int64_t)p.n_terms_total * per) return;
+    const int ti = (int)(gid / per);
+    const int tile = (int)(gid - (int64_t)ti * per);
+    const int term = p.qterms[ti];
+    uint32_t result = 0;
+    if (term >= 0) {
+        const int64_t lo0 = p.indptr[term], hi0 = p.indptr[term + 1];
+        const uint64_t target = (uint64_t)tile * BM_TILE;
+        int64_t lo = lo0, hi = hi0;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)p.rows[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        result = (uint32_t)(lo - lo0);
+    }
+    p.toff[gid] = result;
+}
+
+template <bool SCORES_ONLY>
+__global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
+    __shared__ double acc[BM_TILE];
+    __shared__ uint32_t sel_lds[RAG_SEL_LDS_WORDS];
+    __shared__ unsigned long long tau_s;
+    __shared__ unsigned long long kmin_s;
+    __shared__ int count_s[2];
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x / p.n_queries;
+    const int q = blockIdx.x - tile * p.n_queries;
+    const int64_t r0 = (int64_t)tile * BM_TILE;
+    const int n_in = (int)min((int64_t)BM_TILE, p.n_docs - r0);
+
+    for (int i = tid; i < BM_TILE; i += BM_NT) acc[i] = 0.0;
+    if (tid == 0) {
+        count_s[0] = 0;
+        count_s[1] = 0;
+        kmin_s = ~0ull;
+        tau_s = SCORES_ONLY ? 0ull : __hip_atomic_load(&p.tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+
+    const int t_begin = p.qoff[q], t_end = p.qoff[q + 1];
+    const int per = p.n_tiles + 1;
+    for (int ti = t_begin; ti < t_end; ++ti) {
+        const int term = p.qterms[ti];
+        if (term < 0) continue;                       // out of vocabulary: contributes nothing
+        const int64_t base = p.indptr[term];
+        const int64_t lo = base + p.toff[(int64_t)ti * per + tile];
+        const int64_t hi = base + p.toff[(int64_t)ti * per + tile + 1];
+        const double w = p.idf[term];
+        for (int64_t at = lo + tid; at < hi; at += BM_NT) {
+            const int r = (int)((int64_t)p.rows[at] - r0);
+            // score += idf * impact, two roundings, no contraction
+            acc[r] = __dadd_rn(acc[r], __dmul_rn(w, p.impact[at]));
+        }
+        __syncthreads();
+    }
+
+    if (SCORES_ONLY) {
+        for (int i = tid; i < n_in; i += BM_NT) p.dense_out[r0 + i] = acc[i];
+        return;
+    }
+
+    // ---- how many documents of this tile reach the shared threshold?
+    const unsigned long long tau = tau_s;
+    int mine = 0;
+    for (int i = tid; i < n_in; i += BM_NT) mine += f64_to_key(acc[i]) >= tau ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((tid & 63) == 0 && mine) atomicAdd(&count_s[0], mine);
+    __syncthreads();
+    const int n_pass = count_s[0];
+
+    const size_t slot = ((size_t)q * p.n_tiles + tile) * p.k;
+    if (n_pass <= p.k) {
+        for (int i = tid; i < n_in; i += BM_NT) {
+            unsigned long long key = f64_to_key(acc[i]);
+            if (key >= tau) {
+                int at = atomicAdd(&count_s[1], 1);
+                p.cand_key[slot + at] = key;
+                p.cand_row[slot + at] = (uint32_t)(r0 + i);
+            }
+        }
+    } else {
+        auto get = [&](int i, uint64_t& key, uint32_t& row) {
+            key = f64_to_key(acc[i]);
+            row = (uint32_t)(r0 + i);
+        };
+        SelThr<uint64_t> thr = radix_select<uint64_t, BM_NT>(get, n_in, p.k, sel_lds, tid);
+        unsigned long long kmin = ~0ull;
+        for (int i = tid; i < n_in; i += BM_NT) {
+            uint64_t key = f64_to_key(acc[i]);
+            uint32_t row = (uint32_t)(r0 + i);
+            if (sel_pass(thr, key, row)) {
+                int at = atomicAdd(&count_s[1], 1);
+                p.cand_key[slot + at] = key;
+                p.cand_row[slot + at] = row;
+                kmin = min(kmin, (unsigned long long)key);
+            }
+        }
+        if (kmin != ~0ull) atomicMin(&kmin_s, kmin);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p.cand_count[(size_t)q * p.n_tiles + tile] = count_s[1];
+        if (n_pass > p.k) atomicMax(&p.tau[q], kmin_s);
+    }
+}
+
+}  // namespace
+
+struct rag_bm25_s {
+    int64_t* indptr = nullptr;
+    uint32_t* rows = nullptr;
+    double* impact = nullptr;
+    double* idf = nullptr;
+    bool owns = false;
+    int64_t n_docs = 0, vocab = 0, nnz = 0, row_base = 0;
+    DevBuf toff, tau, cand_key, cand_row, cand_count;
+};
+
+extern "C" int rag_bm25_create(const int64_t* indptr, const uint32_t* rows, const double* impact, const double* idf,
+                               int64_t n_docs, int64_t vocab, int32_t mem_kind, int64_t row_base, rag_bm25_t* out) {
+    RAG_REQUIRE(out != nullptr, RAG_EINVAL, "rag_bm25_create: out is null");
+    *out = nullptr;
+    RAG_REQUIRE(indptr && idf, RAG_EINVAL, "rag_bm25_create: null pointer");
+    RAG_REQUIRE(n_docs >= 0 && vocab >= 0, RAG_EINVAL, "rag_bm25_create: negative size");
+    RAG_REQUIRE(row_base >= 0 && row_base + n_docs < (1ll << 32), RAG_ELIMIT,
+                "rag_bm25_create: global rows must stay below 2^32");
+    RAG_REQUIRE(mem_kind >= RAG_MEM_HOST_COPY && mem_kind <= RAG_MEM_DEVICE_BORROW, RAG_EINVAL,
+                "rag_bm25_create: unknown mem_kind %d", mem_kind);
+    int64_t nnz = 0;
+    if (mem_kind == RAG_MEM_HOST_COPY) {
+        nnz = indptr[vocab];
+    } else {
+        RAG_HIP_TRY(hipMemcpy(&nnz, indptr + vocab, sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    RAG_REQUIRE(nnz >= 0 && nnz < (1ll << 32), RAG_ELIMIT, "rag_bm25_create: %lld postings out of range", (long long)nnz);
+    RAG_REQUIRE(nnz == 0 || (rows && impact), RAG_EINVAL, "rag_bm25_create: null postings");
+    rag_bm25_s* h = new rag_bm25_s();
+    h->n_docs = n_docs;
+    h->vocab = vocab;
+    h->nnz = nnz;
+    h->row_base = row_base;
+    if (mem_kind == RAG_MEM_DEVICE_BORROW) {
+        h->indptr = const_cast<int64_t*>(indptr);
+        h->rows = const_cast<uint32_t*>(rows);
+        h->impact = const_cast<double*>(impact);
+        h->idf = const_cast<double*>(idf);
+    } else {
+        h->owns = true;
+        const hipMemcpyKind kind = mem_kind == RAG_MEM_HOST_COPY ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+            size_t alloc = bytes ? bytes : 16;
+            hipError_t e = hipMalloc(dst, alloc);
+            if (e != hipSuccess) { rag_set_error("rag_bm25_create: hipMalloc(%zu) failed: %s", alloc, hipGetErrorString(e)); return RAG_ENOMEM; }
+            if (bytes) {
+                e = hipMemcpy(*dst, src, bytes, kind);
+                if (e != hipSuccess) { rag_set_error("rag_bm25_create: hipMemcpy failed: %s", hipGetErrorString(e)); return RAG_EHIP; }
+            }
+            return RAG_OK;
+        };
+        int rc = up((void**)&h->indptr, indptr, (size_t)(vocab + 1) * sizeof(int64_t));
+        if (!rc) rc = up((void**)&h->rows, rows, (size_t)nnz * sizeof(uint32_t));
+        if (!rc) rc = up((void**)&h->impact, impact, (size_t)nnz * sizeof(double));
+        if (!rc) rc = up((void**)&h->idf, idf, (size_t)vocab * sizeof(double));
+        if (rc) {
+            rag_bm25_destroy(h);
+            return rc;
+        }
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+extern "C" int rag_bm25_destroy(rag_bm25_t h) {
+    if (!h) return RAG_OK;
+    if (h->owns) {
+        if (h->indptr) (void)hipFree(h->indptr);
+        if (h->rows) (void)hipFree(h->rows);
+        if (h->impact) (void)hipFree(h->impact);
+        if (h->idf) (void)hipFree(h->idf);
+    }
+    h->toff.release();
+    h->tau.release();
+    h->cand_key.release();
+    h->cand_row.release();
+    h->cand_count.release();
+    delete h;
+    return RAG_OK;
+}
+
+extern "C" int64_t rag_bm25_docs(rag_bm25_t h) { return h ? h->n_docs : -1; }
+
+namespace {
+
+int bm25_prepare(rag_bm25_t h, Bm25Params& p, const int32_t* d_qterms, const int32_t* d_qoff, int n_queries,
+                 int n_terms_total, hipStream_t stream) {
+    p.indptr = h->indptr;
+    p.rows = h->rows;
+    p.impact = h->impact;
+    p.idf = h->idf;
+    p.n_docs = h->n_docs;
+    p.qterms = d_qterms;
+    p.qoff = d_qoff;
+    p.n_queries = n_queries;
+    p.n_terms_total = n_terms_total;
+    p.n_tiles = (int)ceil_div64(h->n_docs, BM_TILE);
+    int rc = h->toff.ensure(((size_t)n_terms_total * (p.n_tiles + 1) + 1) * sizeof(uint32_t));
+    if (rc) return rc;
+    p.toff = (uint32_t*)h->toff.p;
+    if (n_terms_total > 0) {
+        const int64_t n = (int64_t)n_terms_total * (p.n_tiles + 1);
+        bm25_offsets_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(p);
+        RAG_HIP_TRY(hipGetLastError());
+    }
+    return RAG_OK;
+}
+
+}  // namespace
+
+extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
+                                   int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row,
+                                   int32_t* d_out_count, void* stream_) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_bm25_search: null handle");
+    RAG_REQUIRE(n_queries >= 0 && n_terms_total >= 0 && k >= 1 && k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_bm25_search: need n_queries >= 0 and 1 <= k <= %d (got %d, %d)", RAG_MAX_K, n_queries, k);
+    if (n_queries == 0) return RAG_OK;
+    RAG_REQUIRE(d_qoff && d_out_score && d_out_row && d_out_count && (d_qterms || n_terms_total == 0), RAG_EINVAL,
+                "rag_bm25_search: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h->n_docs == 0) {
+        RAG_HIP_TRY(hipMemsetAsync(d_out_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
+        RAG_HIP_TRY(hipMemsetAsync(d_out_row, 0xff, (size_t)n_queries * k * sizeof(int64_t), stream));
+        RAG_HIP_TRY(hipMemsetAsync(d_out_score, 0, (size_t)n_queries * k * sizeof(double), stream));
+        return RAG_OK;
+    }
+    Bm25Params p;
+    memset(&p, 0, sizeof(p));
+    int rc = bm25_prepare(h, p, d_qterms, d_qoff, n_queries, n_terms_total, stream);
+    if (rc) return rc;
+    p.k = k;
+    const size_t slots = (size_t)n_queries * p.n_tiles;
+    if ((rc = h->tau.ensure((size_t)n_queries * sizeof(unsigned long long)))) return rc;
+    if ((rc = h->cand_key.ensure(slots * k * sizeof(uint64_t)))) return rc;
+    if ((rc = h->cand_row.ensure(slots * k * sizeof(uint32_t)))) return rc;
+    if ((rc = h->cand_count.ensure(slots * sizeof(int32_t)))) return rc;
+    p.tau = (unsigned long long*)h->tau.p;
+    p.cand_key = (uint64_t*)h->cand_key.p;
+    p.cand_row = (uint32_t*)h->cand_row.p;
+    p.cand_count = (int32_t*)h->cand_count.p;
+    RAG_HIP_TRY(hipMemsetAsync(p.tau, 0, (size_t)n_queries * sizeof(unsigned long long), stream));
+    const int64_t n_blocks = (int64_t)p.n_tiles * n_queries;
+    RAG_REQUIRE(n_blocks < (1ll << 31), RAG_ELIMIT, "rag_bm25_search: %lld workgroups exceed the grid limit",
+                (long long)n_blocks);
+    bm25_tile_kernel<false><<<(unsigned)n_blocks, BM_NT, 0, stream>>>(p);
+    RAG_HIP_TRY(hipGetLastError());
+    return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, p.n_tiles, k, k, h->row_base,
+                               d_out_score, d_out_row, d_out_count, stream);
+}
+
+#define BM_TRY_OR_CLEAN(expr)                                                                    \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            rag_set_error("%s failed: %s", #expr, hipGetErrorString(_e));                        \
+            cleanup();                                                                           \
+            return RAG_EHIP;                                                                     \
+        }                                                                                        \
+    } while (0)
+
+extern "C" int rag_bm25_search(rag_bm25_t h, const int32_t* qterms, const int32_t* qoff, int32_t n_queries, int32_t k,
+                               double* out_score, int64_t* out_row, int32_t* out_count) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_bm25_search: null handle");
+    RAG_REQUIRE(n_queries >= 0 && k >= 1 && k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_bm25_search: need n_queries >= 0 and 1 <= k <= %d (got %d, %d)", RAG_MAX_K, n_queries, k);
+    if (n_queries == 0) return RAG_OK;
+    RAG_REQUIRE(qoff && out_score && out_row && out_count, RAG_EINVAL, "rag_bm25_search: null pointer");
+    const int n_terms = qoff[n_queries];
+    RAG_REQUIRE(qoff[0] == 0 && n_terms >= 0 && (qterms || n_terms == 0), RAG_EINVAL, "rag_bm25_search: bad query offsets");
+    const size_t nk = (size_t)n_queries * k;
+    int32_t *d_t = nullptr, *d_o = nullptr, *d_c = nullptr;
+    double* d_s = nullptr;
+    int64_t* d_r = nullptr;
+    auto cleanup = [&]() {
+        if (d_t) (void)hipFree(d_t);
+        if (d_o) (void)hipFree(d_o);
+        if (d_c) (void)hipFree(d_c);
+        if (d_s) (void)hipFree(d_s);
+        if (d_r) (void)hipFree(d_r);
+    };
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_t, (size_t)(n_terms + 1) * sizeof(int32_t)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_o, (size_t)(n_queries + 1) * sizeof(int32_t)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_c, (size_t)n_queries * sizeof(int32_t)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_s, nk * sizeof(double)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_r, nk * sizeof(int64_t)));
+    if (n_terms) BM_TRY_OR_CLEAN(hipMemcpy(d_t, qterms, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice));
+    BM_TRY_OR_CLEAN(hipMemcpy(d_o, qoff, (size_t)(n_queries + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    int rc = rag_bm25_search_dev(h, d_t, d_o, n_queries, n_terms, k, d_s, d_r, d_c, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    BM_TRY_OR_CLEAN(hipMemcpy(out_score, d_s, nk * sizeof(double), hipMemcpyDeviceToHost));
+    BM_TRY_OR_CLEAN(hipMemcpy(out_row, d_r, nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+    BM_TRY_OR_CLEAN(hipMemcpy(out_count, d_c, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost));
+    cleanup();
+    return RAG_OK;
+}
+
+extern "C" int rag_bm25_scores(rag_bm25_t h, const int32_t* qterms, int32_t n_terms, double* out_scores) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_bm25_scores: null handle");
+    RAG_REQUIRE(n_terms >= 0 && (qterms || n_terms == 0) && out_scores, RAG_EINVAL, "rag_bm25_scores: bad argument");
+    if (h->n_docs == 0) return RAG_OK;
+    int32_t *d_t = nullptr, *d_o = nullptr;
+    double* d_s = nullptr;
+    auto cleanup = [&]() {
+        if (d_t) (void)hipFree(d_t);
+        if (d_o) (void)hipFree(d_o);
+        if (d_s) (void)hipFree(d_s);
+    };
+    const int32_t qoff[2] = {0, n_terms};
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_t, (size_t)(n_terms + 1) * sizeof(int32_t)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_o, 2 * sizeof(int32_t)));
+    BM_TRY_OR_CLEAN(hipMalloc((void**)&d_s, (size_t)h->n_docs * sizeof(double)));
+    if (n_terms) BM_TRY_OR_CLEAN(hipMemcpy(d_t, qterms, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice));
+    BM_TRY_OR_CLEAN(hipMemcpy(d_o, qoff, sizeof(qoff), hipMemcpyHostToDevice));
+    Bm25Params p;
+    memset(&p, 0, sizeof(p));
+    int rc = bm25_prepare(h, p, d_t, d_o, 1, n_terms, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    p.dense_out = d_s;
+    bm25_tile_kernel<true><<<(unsigned)p.n_tiles, BM_NT>>>(p);
+    BM_TRY_OR_CLEAN(hipGetLastError());
+    BM_TRY_OR_CLEAN(hipMemcpy(out_scores, d_s, (size_t)h->n_docs * sizeof(double), hipMemcpyDeviceToHost));
+    cleanup();
+    return RAG_OK;
+}

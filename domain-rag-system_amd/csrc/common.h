@@ -1,0 +1,190 @@
+// Shared host/device helpers for librag_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/rag_hip.h"
+
+// ---------------------------------------------------------------------------------
+// host side: error reporting
+// ---------------------------------------------------------------------------------
+void rag_set_error(const char* fmt, ...);
+
+#define RAG_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            rag_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                          __FILE__, __LINE__);                                         \
+            return RAG_EHIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+#define RAG_REQUIRE(cond, code, ...)                                                   \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            rag_set_error(__VA_ARGS__);                                                \
+            return (code);                                                             \
+        }                                                                              \
+    } while (0)
+
+// Grow-only device buffer owned by a handle (steady-state calls never allocate).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return RAG_OK;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) { rag_set_error("hipFree failed: %s", hipGetErrorString(e)); return RAG_EHIP; }
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            rag_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return RAG_ENOMEM;
+        }
+        cap = want;
+        return RAG_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------
+// device side: order-preserving integer keys for floating-point scores
+// (larger key <=> larger score; -0 and +0 map to the same key)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_to_key(float s) {
+    s += 0.0f;                               // -0 -> +0
+    uint32_t u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_f32(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t f64_to_key(double s) {
+    s += 0.0;
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_f64(uint64_t k) {
+    uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// ---------------------------------------------------------------------------------
+// device side: exact top-K threshold by most-significant-digit radix select
+//
+// Items are (key, row) pairs ordered lexicographically, larger = better; rows are
+// unique, so the K-th best item is unique.  radix_select returns a masked-prefix
+// threshold `t` such that exactly K items satisfy sel_pass(t, key, row).
+// ---------------------------------------------------------------------------------
+template <typename KeyT>
+struct SelThr {
+    KeyT pk, mk;       // determined high bytes of the key and their mask
+    uint32_t pr, mr;   // determined high bytes of the row and their mask
+};
+
+template <typename KeyT>
+__device__ __forceinline__ bool sel_pass(const SelThr<KeyT>& t, KeyT key, uint32_t row) {
+    KeyT a = key & t.mk;
+    return a > t.pk || (a == t.pk && (row & t.mr) >= t.pr);
+}
+
+// LDS scratch needed by one radix_select group: 256 histogram bins + 4 broadcast words.
+#define RAG_SEL_LDS_WORDS 260
+
+// NT = threads in the cooperating group: 64 (one wave, other waves of the block may be
+// doing something else) or the whole block (then every thread of the block must call).
+// get(i, key, row) loads item i; n = number of items; requires 1 <= K <= n.
+template <typename KeyT, int NT, typename Get>
+__device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds, int tid) {
+    constexpr int KEY_BYTES = (int)sizeof(KeyT);
+    uint32_t* hist = lds;
+    uint32_t* bc = lds + 256;
+    SelThr<KeyT> t;
+    t.pk = 0; t.mk = 0; t.pr = 0; t.mr = 0;
+    uint32_t krem = (uint32_t)K;
+
+    auto gsync = [&]() {
+        if constexpr (NT == 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __syncthreads();
+        }
+    };
+
+    for (int pass = 0; pass < KEY_BYTES + 4; ++pass) {
+        for (int b = tid; b < 256; b += NT) hist[b] = 0;
+        gsync();
+        const bool on_key = pass < KEY_BYTES;
+        const int shift = on_key ? 8 * (KEY_BYTES - 1 - pass) : 8 * (3 - (pass - KEY_BYTES));
+        for (int i = tid; i < n; i += NT) {
+            KeyT key; uint32_t row;
+            get(i, key, row);
+            bool match;
+            uint32_t digit;
+            if (on_key) {
+                match = (key & t.mk) == t.pk;
+                digit = (uint32_t)(key >> shift) & 255u;
+            } else {
+                match = (key == t.pk) && ((row & t.mr) == t.pr);
+                digit = (row >> shift) & 255u;
+            }
+            if (match) atomicAdd(&hist[digit], 1u);
+        }
+        gsync();
+        // one wave finds the digit d with  #(digit > d) < krem <= #(digit >= d)
+        if (tid < 64) {
+            const int l = tid;
+            uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            uint32_t s = h0 + h1 + h2 + h3;
+            uint32_t v = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t o = __shfl_down(v, off, 64);
+                if (l + off < 64) v += o;
+            }
+            uint32_t c = v - s;                    // items in bins above this lane's four
+            uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (c < krem && krem <= c + hh[j]) {
+                    bc[0] = (uint32_t)(4 * l + j);  // the digit
+                    bc[1] = c;                      // items strictly above it
+                    bc[2] = hh[j];                  // items in it
+                }
+                c += hh[j];
+            }
+        }
+        gsync();
+        const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
+        if (on_key) {
+            t.pk |= (KeyT)d << shift;
+            t.mk |= (KeyT)255u << shift;
+        } else {
+            t.pr |= d << shift;
+            t.mr |= 255u << shift;
+        }
+        krem -= above;
+        if (inbin == krem) break;               // every item of this bin is wanted
+    }
+    gsync();
+    return t;
+}

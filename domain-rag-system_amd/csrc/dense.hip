@@ -1,0 +1,637 @@
+// Exact dense kNN over a resident [N x D] fp32 matrix: fp32 MFMA tile GEMM fused with a
+// per-query running top-K, then a per-query merge.  gfx950 (MI355X) only.
+//
+// Replaces the embedded Qdrant store and its brute-force query_points call behind
+// VectorIndexer.search (reference src/indexing/vector_indexer.py:165-230).
+//
+// Layout in HBM: rows[N][D] fp32 row-major (already L2-normalised for cosine),
+// row_norm2[N] fp32 only for the Euclidean metric.
+//
+// Kernel 1 (dense_scan_kernel): the grid is (query blocks) x (row strips).  A workgroup
+// keeps BQ queries against one strip of rows: per 128-row tile it accumulates the
+// [rows x queries] score tile with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains) from
+// LDS-staged, double-buffered k-slices, and in the tile epilogue appends every score that
+// reaches the query's running threshold to that query's candidate list.  When a list is
+// about to overflow, one wave radix-selects its K best, which also raises the threshold.
+// Kernel 2 (merge_topk_kernel, in merge.h): per query, selects and sorts the K best of
+// the per-strip lists.
+#include "common.h"
+#include "merge.h"
+
+#include <math.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;          // k-slice per stage
+constexpr int LDK = BK + 4;     // padded LDS row (floats): conflict-free ds_read_b128
+constexpr int BN = 128;         // rows per tile
+
+struct DenseScanParams {
+    const float* rows;          // [n_rows][dim]
+    const float* queries;       // [n_queries][dim]
+    const float* row_norm2;     // [n_rows] or null (Euclidean only)
+    const uint8_t* row_mask;    // [n_rows] or null
+    int64_t n_rows;
+    int dim;
+    int n_queries;
+    int k;                      // wanted per query
+    int cap;                    // candidate list capacity per (block, query), >= k + BN
+    int n_strips;               // multiple of 8
+    int n_qblocks;
+    int64_t strip_rows;         // multiple of BN
+    uint2* scratch;             // [n_blocks][BQ][cap]  (key, local row)
+    uint2* cand;                // [n_queries][n_strips][k]
+    int32_t* cand_count;        // [n_queries][n_strips]
+    int euclid;
+};
+
+template <int WQ, int TQ, int WR, int TR>
+struct DenseCfg {
+    static constexpr int NW = WQ * WR;
+    static constexpr int NT = NW * 64;
+    static constexpr int BQ = WQ * TQ * 32;
+    static_assert(WR * TR * 32 == BN, "row tile must be BN rows");
+    static constexpr int E_LOADS = BN * (BK / 4) / NT;
+    static constexpr int Q_LOADS = (BQ * (BK / 4) + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES =
+        (size_t)2 * (BN + BQ) * LDK * sizeof(float) + BQ * 8 + NW * RAG_SEL_LDS_WORDS * 4;
+};
+
+// One wave: keep the K best of the n candidates of one query (in place), return the
+// smallest kept key.
+__device__ inline uint32_t wave_compact(uint2* list, int n, int K, uint32_t* sel_lds, int lane) {
+    auto get = [&](int i, uint32_t& key, uint32_t& row) {
+        uint2 v = list[i];
+        key = v.x;
+        row = v.y;
+    };
+    SelThr<uint32_t> thr = radix_select<uint32_t, 64>(get, n, K, sel_lds, lane);
+    int w = 0;
+    uint32_t kmin = 0xffffffffu;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        uint2 v = make_uint2(0, 0);
+        bool keep = false;
+        if (i < n) {
+            v = list[i];
+            keep = sel_pass(thr, v.x, v.y);
+        }
+        unsigned long long m = __ballot(keep);
+        if (keep) {
+            int pos = w + __popcll(m & ((1ull << lane) - 1ull));
+            list[pos] = v;
+            kmin = min(kmin, v.x);
+        }
+        w += __popcll(m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return kmin;
+}
+
+template <int WQ, int TQ, int WR, int TR, bool EUCLID>
+__global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanParams p) {
+    using Cfg = DenseCfg<WQ, TQ, WR, TR>;
+    constexpr int NT = Cfg::NT, NW = Cfg::NW, BQ = Cfg::BQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* Es = reinterpret_cast<float*>(smem_raw);                 // [2][BN][LDK]
+    float* Qs = Es + 2 * BN * LDK;                                  // [2][BQ][LDK]
+    int* cnt_s = reinterpret_cast<int*>(Qs + 2 * BQ * LDK);         // [BQ]
+    float* tau_s = reinterpret_cast<float*>(cnt_s + BQ);            // [BQ]
+    uint32_t* sel_s = reinterpret_cast<uint32_t*>(tau_s + BQ);      // [NW][RAG_SEL_LDS_WORDS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wq = wave / WR, wr = wave % WR;
+
+    // blocks that share a strip get the same blockIdx % 8 (one XCD's L2 under round-robin
+    // placement: a speed choice only)
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int qb = j % p.n_qblocks;
+    const int strip = (j / p.n_qblocks) * 8 + xcd;
+    const int q0 = qb * BQ;
+
+    const int64_t row_begin = (int64_t)strip * p.strip_rows;
+    const int64_t row_end = min(p.n_rows, row_begin + p.strip_rows);
+    uint2* my_scratch = p.scratch + (size_t)blockIdx.x * BQ * p.cap;
+
+    for (int i = tid; i < BQ; i += NT) {
+        cnt_s[i] = 0;
+        tau_s[i] = -INFINITY;
+    }
+    __syncthreads();
+
+    const int n_tiles = row_begin < row_end ? (int)((row_end - row_begin + BN - 1) / BN) : 0;
+    const int k_stages = (p.dim + BK - 1) / BK;
+    const int n_stages = n_tiles * k_stages;
+
+    float4 e_reg[Cfg::E_LOADS];
+    float4 q_reg[Cfg::Q_LOADS];
+
+    auto stage_load = [&](int st) {
+        const int tile = st / k_stages;
+        const int kb = (st - tile * k_stages) * BK;
+        const int64_t trow0 = row_begin + (int64_t)tile * BN;
+#pragma unroll
+        for (int i = 0; i < Cfg::E_LOADS; ++i) {
+            int idx = tid + i * NT;
+            int r = idx >> 3, k4 = (idx & 7) * 4;
+            int64_t grow = trow0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < row_end && kb + k4 < p.dim)
+                v = *reinterpret_cast<const float4*>(p.rows + grow * p.dim + kb + k4);
+            e_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::Q_LOADS; ++i) {
+            int idx = tid + i * NT;
+            int r = idx >> 3, k4 = (idx & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BQ && q0 + r < p.n_queries && kb + k4 < p.dim)
+                v = *reinterpret_cast<const float4*>(p.queries + (int64_t)(q0 + r) * p.dim + kb + k4);
+            q_reg[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* eb = Es + buf * BN * LDK;
+        float* qbuf = Qs + buf * BQ * LDK;
+#pragma unroll
+        for (int i = 0; i < Cfg::E_LOADS; ++i) {
+            int idx = tid + i * NT;
+            int r = idx >> 3, k4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(eb + r * LDK + k4) = e_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::Q_LOADS; ++i) {
+            int idx = tid + i * NT;
+            int r = idx >> 3, k4 = (idx & 7) * 4;
+            if (r < BQ) *reinterpret_cast<float4*>(qbuf + r * LDK + k4) = q_reg[i];
+        }
+    };
+
+    f32x16 acc[TQ][TR];
+#pragma unroll
+    for (int a = 0; a < TQ; ++a)
+#pragma unroll
+        for (int b = 0; b < TR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (n_stages > 0) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    const int lrow = lane & 31;           // row of the A tile / column (query) of the B tile
+    const int khalf = (lane >> 5) * 4;    // which half of each 8-wide k group this lane feeds
+
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < n_stages) stage_load(st + 1);
+
+        const float* eb = Es + buf * BN * LDK;
+        const float* qbuf = Qs + buf * BQ * LDK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 a[TR], b[TQ];
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+                a[tr] = *reinterpret_cast<const float4*>(eb + ((wr * TR + tr) * 32 + lrow) * LDK + kk * 8 + khalf);
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq)
+                b[tq] = *reinterpret_cast<const float4*>(qbuf + ((wq * TQ + tq) * 32 + lrow) * LDK + kk * 8 + khalf);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+                    for (int tr = 0; tr < TR; ++tr) {
+                        float av = c == 0 ? a[tr].x : c == 1 ? a[tr].y : c == 2 ? a[tr].z : a[tr].w;
+                        float bv = c == 0 ? b[tq].x : c == 1 ? b[tq].y : c == 2 ? b[tq].z : b[tq].w;
+                        acc[tq][tr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tq][tr], 0, 0, 0);
+                    }
+            }
+        }
+
+        const int tile = st / k_stages;
+        if (st - tile * k_stages == k_stages - 1) {
+            // ---- tile epilogue: D[i][j], i = row (register + lane half), j = query (lane & 31)
+            const int64_t trow0 = row_begin + (int64_t)tile * BN;
+            const int rows_in_tile = (int)min((int64_t)BN, row_end - trow0);
+            const int rbase = wr * TR * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int tq = 0; tq < TQ; ++tq) {
+                const int ql = (wq * TQ + tq) * 32 + lrow;
+                const bool qvalid = q0 + ql < p.n_queries;
+                const float tauq = tau_s[ql];
+#pragma unroll
+                for (int tr = 0; tr < TR; ++tr) {
+                    f32x16& a = acc[tq][tr];
+                    if (EUCLID) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                            if (rl < rows_in_tile) a[r] = 2.0f * a[r] - p.row_norm2[trow0 + rl];
+                        }
+                    }
+                    float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
+                    m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
+                    const bool any = qvalid && m >= tauq;
+                    if (__ballot(any)) {             // rare once the threshold has warmed up
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                            const float sc = a[r];
+                            if (any && rl < rows_in_tile && sc >= tauq) {
+                                const uint32_t grow = (uint32_t)(trow0 + rl);
+                                if (p.row_mask == nullptr || p.row_mask[grow]) {
+                                    int slot = atomicAdd(&cnt_s[ql], 1);
+                                    my_scratch[(size_t)ql * p.cap + slot] = make_uint2(f32_to_key(sc), grow);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+                }
+            }
+            __syncthreads();
+            // ---- lists that could overflow in the next tile are cut back to their K best
+            const bool last_tile = tile == n_tiles - 1;
+            for (int base = wave * (BQ / NW); base < (wave + 1) * (BQ / NW); base += 64) {
+                int ql = base + lane;
+                bool need = false;
+                if (ql < (wave + 1) * (BQ / NW)) {
+                    int c = cnt_s[ql];
+                    need = last_tile ? c > p.k : c > p.cap - BN;
+                }
+                unsigned long long m = __ballot(need);
+                while (m) {
+                    int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    int q = base + b;
+                    int n = cnt_s[q];
+                    uint32_t kmin = wave_compact(my_scratch + (size_t)q * p.cap, n, p.k,
+                                                 sel_s + wave * RAG_SEL_LDS_WORDS, lane);
+                    if (lane == 0) {
+                        cnt_s[q] = p.k;
+                        tau_s[q] = key_to_f32(kmin);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        if (st + 1 < n_stages) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- publish this strip's lists
+    for (int ql = wave * (BQ / NW); ql < (wave + 1) * (BQ / NW); ++ql) {
+        const int q = q0 + ql;
+        if (q >= p.n_queries) break;
+        const int n = min(cnt_s[ql], p.k);
+        uint2* dst = p.cand + ((size_t)q * p.n_strips + strip) * p.k;
+        const uint2* src = my_scratch + (size_t)ql * p.cap;
+        for (int i = lane; i < n; i += 64) dst[i] = src[i];
+        if (lane == 0) p.cand_count[(size_t)q * p.n_strips + strip] = n;
+    }
+}
+
+// Exact score of chosen (query, row) pairs: one wave per pair.
+__global__ void dense_rescore_kernel(const float* __restrict__ rows, const float* __restrict__ queries,
+                                     const int64_t* __restrict__ cand, float* __restrict__ out,
+                                     int64_t n_pairs, int m, int dim, int64_t row_base, int64_t n_rows,
+                                     int euclid) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
+    const int64_t q = pair / m;
+    const int64_t row = cand[pair] - row_base;
+    float s = 0.f;
+    if (row >= 0 && row < n_rows) {
+        const float* e = rows + row * dim;
+        const float* qv = queries + q * dim;
+        for (int k = lane * 4; k < dim; k += 256) {
+            float4 a = *reinterpret_cast<const float4*>(e + k);
+            float4 b = *reinterpret_cast<const float4*>(qv + k);
+            if (euclid) {
+                float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+                s += dx * dx + dy * dy + dz * dz + dw * dw;
+            } else {
+                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (euclid) s = sqrtf(s);
+    }
+    if (lane == 0) out[pair] = s;
+}
+
+__global__ void row_norm2_kernel(const float* __restrict__ rows, float* __restrict__ out, int64_t n_rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* e = rows + row * dim;
+    float s = 0.f;
+    for (int k = lane * 4; k < dim; k += 256) {
+        float4 a = *reinterpret_cast<const float4*>(e + k);
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[row] = s;
+}
+
+// Euclidean finish: the scan ranks by 2 q.e - |e|^2; turn that into a distance.
+__global__ void euclid_finish_kernel(float* score, const int32_t* count, const float* queries, int n_queries,
+                                     int k, int dim) {
+    const int q = blockIdx.x;
+    __shared__ float qn_s;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        float v = queries[(int64_t)q * dim + i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) qn_s = s;   // blockDim.x == 64
+    __syncthreads();
+    for (int i = threadIdx.x; i < count[q]; i += blockDim.x) {
+        float v = qn_s - score[(int64_t)q * k + i];
+        score[(int64_t)q * k + i] = sqrtf(fmaxf(v, 0.f));
+    }
+}
+
+}  // namespace
+
+struct rag_dense_s {
+    float* rows = nullptr;
+    float* row_norm2 = nullptr;
+    bool owns_rows = false;
+    int64_t n_rows = 0;
+    int dim = 0;
+    int metric = 0;
+    int64_t row_base = 0;
+    int device = 0;
+    DevBuf scratch, cand, cand_count;
+};
+
+extern "C" int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t metric,
+                                int32_t mem_kind, int64_t row_base, rag_dense_t* out) {
+    RAG_REQUIRE(out != nullptr, RAG_EINVAL, "rag_dense_create: out is null");
+    *out = nullptr;
+    RAG_REQUIRE(rows != nullptr || n_rows == 0, RAG_EINVAL, "rag_dense_create: rows is null");
+    RAG_REQUIRE(n_rows >= 0 && n_rows < (1ll << 32), RAG_ELIMIT, "rag_dense_create: n_rows %lld out of range",
+                (long long)n_rows);
+    RAG_REQUIRE(row_base >= 0 && row_base + n_rows < (1ll << 32), RAG_ELIMIT,
+                "rag_dense_create: global rows must stay below 2^32");
+    RAG_REQUIRE(dim > 0 && dim % 4 == 0, RAG_EINVAL, "rag_dense_create: dim %d must be a positive multiple of 4", dim);
+    RAG_REQUIRE(metric >= RAG_METRIC_COSINE && metric <= RAG_METRIC_EUCLID, RAG_EINVAL,
+                "rag_dense_create: unknown metric %d", metric);
+    RAG_REQUIRE(mem_kind >= RAG_MEM_HOST_COPY && mem_kind <= RAG_MEM_DEVICE_BORROW, RAG_EINVAL,
+                "rag_dense_create: unknown mem_kind %d", mem_kind);
+    rag_dense_s* h = new rag_dense_s();
+    h->n_rows = n_rows;
+    h->dim = dim;
+    h->metric = metric;
+    h->row_base = row_base;
+    RAG_HIP_TRY(hipGetDevice(&h->device));
+    const size_t bytes = (size_t)n_rows * dim * sizeof(float);
+    if (mem_kind == RAG_MEM_DEVICE_BORROW) {
+        h->rows = const_cast<float*>(rows);
+    } else if (n_rows > 0) {
+        hipError_t e = hipMalloc((void**)&h->rows, bytes);
+        if (e != hipSuccess) {
+            delete h;
+            rag_set_error("rag_dense_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return RAG_ENOMEM;
+        }
+        h->owns_rows = true;
+        e = hipMemcpy(h->rows, rows, bytes,
+                      mem_kind == RAG_MEM_HOST_COPY ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(h->rows);
+            delete h;
+            rag_set_error("rag_dense_create: hipMemcpy failed: %s", hipGetErrorString(e));
+            return RAG_EHIP;
+        }
+    }
+    if (metric == RAG_METRIC_EUCLID && n_rows > 0) {
+        hipError_t e = hipMalloc((void**)&h->row_norm2, (size_t)n_rows * sizeof(float));
+        if (e != hipSuccess) {
+            if (h->owns_rows) (void)hipFree(h->rows);
+            delete h;
+            rag_set_error("rag_dense_create: hipMalloc(norms) failed: %s", hipGetErrorString(e));
+            return RAG_ENOMEM;
+        }
+        row_norm2_kernel<<<(unsigned)ceil_div64(n_rows, 4), 256>>>(h->rows, h->row_norm2, n_rows, dim);
+        RAG_HIP_TRY(hipDeviceSynchronize());
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+extern "C" int rag_dense_destroy(rag_dense_t h) {
+    if (!h) return RAG_OK;
+    if (h->owns_rows && h->rows) (void)hipFree(h->rows);
+    if (h->row_norm2) (void)hipFree(h->row_norm2);
+    h->scratch.release();
+    h->cand.release();
+    h->cand_count.release();
+    delete h;
+    return RAG_OK;
+}
+
+extern "C" int64_t rag_dense_rows(rag_dense_t h) { return h ? h->n_rows : -1; }
+
+namespace {
+
+template <int WQ, int TQ, int WR, int TR>
+int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
+    using Cfg = DenseCfg<WQ, TQ, WR, TR>;
+    p.n_qblocks = (p.n_queries + Cfg::BQ - 1) / Cfg::BQ;
+    // about two resident workgroups per CU, strips a multiple of 8 (one per XCD slot)
+    int64_t want_strips = (512 + p.n_qblocks - 1) / p.n_qblocks;
+    int64_t max_strips = ceil_div64(p.n_rows, BN);
+    if (want_strips > max_strips) want_strips = max_strips;
+    if (want_strips < 1) want_strips = 1;
+    p.strip_rows = ceil_div64(ceil_div64(p.n_rows, want_strips), BN) * BN;
+    int64_t strips = ceil_div64(p.n_rows, p.strip_rows);
+    p.n_strips = (int)(ceil_div64(strips, 8) * 8);
+    const int64_t n_blocks = (int64_t)p.n_strips * p.n_qblocks;
+
+    int rc = h->scratch.ensure((size_t)n_blocks * Cfg::BQ * p.cap * sizeof(uint2));
+    if (rc) return rc;
+    rc = h->cand.ensure((size_t)p.n_queries * p.n_strips * p.k * sizeof(uint2));
+    if (rc) return rc;
+    rc = h->cand_count.ensure((size_t)p.n_queries * p.n_strips * sizeof(int32_t));
+    if (rc) return rc;
+    p.scratch = (uint2*)h->scratch.p;
+    p.cand = (uint2*)h->cand.p;
+    p.cand_count = (int32_t*)h->cand_count.p;
+
+    auto kern = p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true> : dense_scan_kernel<WQ, TQ, WR, TR, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[p.euclid]) {
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)Cfg::LDS_BYTES));
+        attr_set[p.euclid] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+}  // namespace
+
+extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32_t n_queries, int32_t k,
+                                    const uint8_t* d_row_mask, float* d_out_score, int64_t* d_out_row,
+                                    int32_t* d_out_count, void* stream_) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_search: null handle");
+    RAG_REQUIRE(n_queries >= 0 && k >= 1 && k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_dense_search: need n_queries >= 0 and 1 <= k <= %d (got %d, %d)", RAG_MAX_K, n_queries, k);
+    RAG_REQUIRE(d_queries && d_out_score && d_out_row && d_out_count, RAG_EINVAL, "rag_dense_search: null pointer");
+    if (n_queries == 0) return RAG_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h->n_rows == 0) {
+        RAG_HIP_TRY(hipMemsetAsync(d_out_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
+        RAG_HIP_TRY(hipMemsetAsync(d_out_row, 0xff, (size_t)n_queries * k * sizeof(int64_t), stream));
+        RAG_HIP_TRY(hipMemsetAsync(d_out_score, 0, (size_t)n_queries * k * sizeof(float), stream));
+        return RAG_OK;
+    }
+    DenseScanParams p;
+    p.rows = h->rows;
+    p.queries = d_queries;
+    p.row_norm2 = h->row_norm2;
+    p.row_mask = d_row_mask;
+    p.n_rows = h->n_rows;
+    p.dim = h->dim;
+    p.n_queries = n_queries;
+    p.k = k;
+    int cap = 2 * k + BN;
+    if (cap < 3 * BN) cap = 3 * BN;
+    p.cap = (cap + 63) / 64 * 64;
+    p.euclid = h->metric == RAG_METRIC_EUCLID;
+    int rc;
+    if (n_queries <= 32)
+        rc = launch_scan<1, 1, 4, 1>(h, p, stream);
+    else if (n_queries <= 64)
+        rc = launch_scan<1, 2, 4, 1>(h, p, stream);
+    else
+        rc = launch_scan<2, 2, 2, 2>(h, p, stream);
+    if (rc) return rc;
+    rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
+                             d_out_row, d_out_count, stream);
+    if (rc) return rc;
+    if (p.euclid) {
+        euclid_finish_kernel<<<n_queries, 64, 0, stream>>>(d_out_score, d_out_count, d_queries, n_queries, k, h->dim);
+        RAG_HIP_TRY(hipGetLastError());
+    }
+    return RAG_OK;
+}
+
+extern "C" int rag_dense_search(rag_dense_t h, const float* queries, int32_t n_queries, int32_t k,
+                                const uint8_t* row_mask, float* out_score, int64_t* out_row, int32_t* out_count) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_search: null handle");
+    RAG_REQUIRE(n_queries >= 0 && k >= 1 && k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_dense_search: need n_queries >= 0 and 1 <= k <= %d (got %d, %d)", RAG_MAX_K, n_queries, k);
+    if (n_queries == 0) return RAG_OK;
+    RAG_REQUIRE(queries && out_score && out_row && out_count, RAG_EINVAL, "rag_dense_search: null pointer");
+    const size_t qb = (size_t)n_queries * h->dim * sizeof(float);
+    const size_t nk = (size_t)n_queries * k;
+    float* d_q = nullptr;
+    uint8_t* d_mask = nullptr;
+    float* d_s = nullptr;
+    int64_t* d_r = nullptr;
+    int32_t* d_c = nullptr;
+    int rc = RAG_OK;
+    auto cleanup = [&]() {
+        if (d_q) (void)hipFree(d_q);
+        if (d_mask) (void)hipFree(d_mask);
+        if (d_s) (void)hipFree(d_s);
+        if (d_r) (void)hipFree(d_r);
+        if (d_c) (void)hipFree(d_c);
+    };
+#define TRY_OR_CLEAN(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            rag_set_error("%s failed: %s", #expr, hipGetErrorString(_e));                        \
+            cleanup();                                                                           \
+            return RAG_EHIP;                                                                     \
+        }                                                                                        \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void**)&d_q, qb));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_s, nk * sizeof(float)));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_r, nk * sizeof(int64_t)));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_c, (size_t)n_queries * sizeof(int32_t)));
+    TRY_OR_CLEAN(hipMemcpy(d_q, queries, qb, hipMemcpyHostToDevice));
+    if (row_mask && h->n_rows > 0) {
+        TRY_OR_CLEAN(hipMalloc((void**)&d_mask, (size_t)h->n_rows));
+        TRY_OR_CLEAN(hipMemcpy(d_mask, row_mask, (size_t)h->n_rows, hipMemcpyHostToDevice));
+    }
+    rc = rag_dense_search_dev(h, d_q, n_queries, k, d_mask, d_s, d_r, d_c, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipMemcpy(out_score, d_s, nk * sizeof(float), hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(out_row, d_r, nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(out_count, d_c, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost));
+    cleanup();
+    return RAG_OK;
+}
+
+extern "C" int rag_dense_rescore_dev(rag_dense_t h, const float* d_queries, int32_t n_queries,
+                                     const int64_t* d_cand_rows, int32_t m, float* d_out_score, void* stream_) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_rescore: null handle");
+    RAG_REQUIRE(n_queries >= 0 && m >= 0, RAG_EINVAL, "rag_dense_rescore: negative size");
+    const int64_t n_pairs = (int64_t)n_queries * m;
+    if (n_pairs == 0) return RAG_OK;
+    RAG_REQUIRE(d_queries && d_cand_rows && d_out_score, RAG_EINVAL, "rag_dense_rescore: null pointer");
+    dense_rescore_kernel<<<(unsigned)ceil_div64(n_pairs, 4), 256, 0, (hipStream_t)stream_>>>(
+        h->rows, d_queries, d_cand_rows, d_out_score, n_pairs, m, h->dim, h->row_base, h->n_rows,
+        h->metric == RAG_METRIC_EUCLID);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_dense_rescore(rag_dense_t h, const float* queries, int32_t n_queries, const int64_t* cand_rows,
+                                 int32_t m, float* out_score) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_rescore: null handle");
+    RAG_REQUIRE(n_queries >= 0 && m >= 0, RAG_EINVAL, "rag_dense_rescore: negative size");
+    const size_t n_pairs = (size_t)n_queries * m;
+    if (n_pairs == 0) return RAG_OK;
+    RAG_REQUIRE(queries && cand_rows && out_score, RAG_EINVAL, "rag_dense_rescore: null pointer");
+    float* d_q = nullptr;
+    int64_t* d_c = nullptr;
+    float* d_o = nullptr;
+    auto cleanup = [&]() {
+        if (d_q) (void)hipFree(d_q);
+        if (d_c) (void)hipFree(d_c);
+        if (d_o) (void)hipFree(d_o);
+    };
+    TRY_OR_CLEAN(hipMalloc((void**)&d_q, (size_t)n_queries * h->dim * sizeof(float)));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_c, n_pairs * sizeof(int64_t)));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_o, n_pairs * sizeof(float)));
+    TRY_OR_CLEAN(hipMemcpy(d_q, queries, (size_t)n_queries * h->dim * sizeof(float), hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(d_c, cand_rows, n_pairs * sizeof(int64_t), hipMemcpyHostToDevice));
+    int rc = rag_dense_rescore_dev(h, d_q, n_queries, d_c, m, d_o, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipMemcpy(out_score, d_o, n_pairs * sizeof(float), hipMemcpyDeviceToHost));
+    cleanup();
+    return RAG_OK;
+#undef TRY_OR_CLEAN
+}

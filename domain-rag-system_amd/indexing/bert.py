@@ -1,0 +1,279 @@
+"""BERT-family encoder forward passes in plain PyTorch (ROCm), plus checkpoint and
+tokenizer loading from a local directory.
+
+PyTorch is used here only for the two transformer forwards of the retrieval path: the
+bi-encoder behind ``MedicalEmbedder.encode`` (reference ``src/indexing/embedder.py:65-71``,
+a sentence-transformers pipeline: BERT -> mean pooling over the attention mask -> L2
+normalise) and the cross-encoder behind ``CrossEncoderReranker.score_pairs`` (reference
+``src/reranker/rerank.py:79-84``, a ``BertForSequenceClassification`` with one label).
+
+Model specs understood by ``load_model``:
+  * a local directory holding ``config.json`` + ``model.safetensors`` or
+    ``pytorch_model.bin`` (+ ``tokenizer.json`` or ``vocab.txt``);
+  * ``random:<arch>`` - seeded random weights of a named architecture and a hash
+    tokenizer, for benchmarks and tests on machines without checkpoints
+    (``bert-base``: 12 layers / 768 hidden; ``minilm-l6``: 6 layers / 384 hidden;
+    ``tiny``: 2 layers / 64 hidden);
+  * anything else is treated as a hub id and resolved from the local Hugging Face cache
+    only; a miss raises (there is no silent fallback model).
+"""
+import json
+import math
+import os
+import re
+import zlib
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class BertConfig:
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    num_labels: int = 1
+
+    @classmethod
+    def from_json(cls, path):
+        with open(path, 'r', encoding='utf-8') as f:
+            raw = json.load(f)
+        keys = cls.__dataclass_fields__.keys()
+        cfg = cls(**{k: raw[k] for k in keys if k in raw})
+        if 'id2label' in raw:
+            cfg.num_labels = len(raw['id2label'])
+        return cfg
+
+
+ARCHS = {
+    'bert-base': BertConfig(),
+    'minilm-l6': BertConfig(hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536),
+    'tiny': BertConfig(vocab_size=4096, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                       intermediate_size=128, max_position_embeddings=512),
+}
+
+
+class BertLayer(nn.Module):
+    def __init__(self, c: BertConfig):
+        super().__init__()
+        self.heads = c.num_attention_heads
+        self.qkv = nn.Linear(c.hidden_size, 3 * c.hidden_size)
+        self.attn_out = nn.Linear(c.hidden_size, c.hidden_size)
+        self.attn_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.ffn_in = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.ffn_out = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.ffn_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+    def forward(self, x, attn_bias):
+        b, s, h = x.shape
+        qkv = self.qkv(x).view(b, s, 3, self.heads, h // self.heads).permute(2, 0, 3, 1, 4)
+        ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=attn_bias)
+        ctx = ctx.transpose(1, 2).reshape(b, s, h)
+        x = self.attn_norm(x + self.attn_out(ctx))
+        return self.ffn_norm(x + self.ffn_out(F.gelu(self.ffn_in(x))))
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, c: BertConfig):
+        super().__init__()
+        self.config = c
+        self.word = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.position = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.emb_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.layers = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None):
+        b, s = input_ids.shape
+        pos = torch.arange(s, device=input_ids.device)
+        x = self.word(input_ids) + self.position(pos)[None, :, :]
+        x = x + self.token_type(token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids))
+        x = self.emb_norm(x)
+        bias = None
+        if attention_mask is not None:
+            bias = torch.zeros((b, 1, 1, s), dtype=x.dtype, device=x.device)
+            bias.masked_fill_(attention_mask[:, None, None, :] == 0, torch.finfo(x.dtype).min)
+        for layer in self.layers:
+            x = layer(x, bias)
+        return x
+
+
+class BiEncoder(nn.Module):
+    """BERT -> mean pooling over real tokens -> (optional) L2 normalisation."""
+
+    def __init__(self, c: BertConfig):
+        super().__init__()
+        self.bert = BertEncoder(c)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, normalize=True):
+        h = self.bert(input_ids, token_type_ids, attention_mask).float()
+        if attention_mask is None:
+            pooled = h.mean(dim=1)
+        else:
+            m = attention_mask.to(h.dtype)[:, :, None]
+            pooled = (h * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
+        return F.normalize(pooled, p=2, dim=1) if normalize else pooled
+
+
+class CrossEncoderModel(nn.Module):
+    """BERT -> tanh pooler on [CLS] -> linear head; one logit per pair when num_labels == 1."""
+
+    def __init__(self, c: BertConfig):
+        super().__init__()
+        self.bert = BertEncoder(c)
+        self.pooler = nn.Linear(c.hidden_size, c.hidden_size)
+        self.classifier = nn.Linear(c.hidden_size, c.num_labels)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None):
+        h = self.bert(input_ids, token_type_ids, attention_mask)
+        logits = self.classifier(torch.tanh(self.pooler(h[:, 0])))
+        return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
+
+
+# ---- checkpoints ---------------------------------------------------------------------------
+def _read_weights(directory):
+    st = os.path.join(directory, 'model.safetensors')
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    pt = os.path.join(directory, 'pytorch_model.bin')
+    if os.path.exists(pt):
+        return torch.load(pt, map_location='cpu', weights_only=True)
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {directory}")
+
+
+def _convert_hf_state(sd, n_layers):
+    """Hugging Face BertModel / BertForSequenceClassification names -> this module's."""
+    sd = {re.sub(r'^(bert\.|0\.auto_model\.|auto_model\.)', '', k): v for k, v in sd.items()}
+    out = {}
+    e = 'embeddings.'
+    out['bert.word.weight'] = sd[e + 'word_embeddings.weight']
+    out['bert.position.weight'] = sd[e + 'position_embeddings.weight']
+    out['bert.token_type.weight'] = sd[e + 'token_type_embeddings.weight']
+    out['bert.emb_norm.weight'] = sd[e + 'LayerNorm.weight']
+    out['bert.emb_norm.bias'] = sd[e + 'LayerNorm.bias']
+    for i in range(n_layers):
+        s, d = f'encoder.layer.{i}.', f'bert.layers.{i}.'
+        for part in ('weight', 'bias'):
+            out[d + 'qkv.' + part] = torch.cat([sd[s + f'attention.self.{n}.{part}'] for n in ('query', 'key', 'value')])
+            out[d + 'attn_out.' + part] = sd[s + 'attention.output.dense.' + part]
+            out[d + 'attn_norm.' + part] = sd[s + 'attention.output.LayerNorm.' + part]
+            out[d + 'ffn_in.' + part] = sd[s + 'intermediate.dense.' + part]
+            out[d + 'ffn_out.' + part] = sd[s + 'output.dense.' + part]
+            out[d + 'ffn_norm.' + part] = sd[s + 'output.LayerNorm.' + part]
+    for part in ('weight', 'bias'):
+        if 'pooler.dense.' + part in sd:
+            out['pooler.' + part] = sd['pooler.dense.' + part]
+        if 'classifier.' + part in sd:
+            out['classifier.' + part] = sd['classifier.' + part]
+    return out
+
+
+# ---- tokenizers ----------------------------------------------------------------------------
+class HashTokenizer:
+    """Deterministic stand-in when no vocabulary exists: lower-cased ``\\w+`` words hashed
+    into the id range above the special tokens."""
+    cls_id, sep_id, pad_id = 101, 102, 0
+    _word = re.compile(r'\w+')
+
+    def __init__(self, vocab_size):
+        if vocab_size <= 200:
+            raise ValueError("hash tokenizer needs a vocabulary above the special-token ids")
+        self.vocab_size = vocab_size
+        self.base = min(1000, vocab_size // 2)
+
+    def encode(self, text):
+        span = self.vocab_size - self.base
+        return [self.base + zlib.crc32(w.encode('utf-8')) % span for w in self._word.findall(text.lower())]
+
+
+class FileTokenizer:
+    """WordPiece tokenizer read from ``tokenizer.json`` or ``vocab.txt`` (``tokenizers`` lib)."""
+
+    def __init__(self, directory):
+        from tokenizers import Tokenizer, BertWordPieceTokenizer
+        tj = os.path.join(directory, 'tokenizer.json')
+        if os.path.exists(tj):
+            self.tok = Tokenizer.from_file(tj)
+            self.tok.no_padding()
+            self.tok.no_truncation()
+        else:
+            vocab = os.path.join(directory, 'vocab.txt')
+            if not os.path.exists(vocab):
+                raise FileNotFoundError(f"no tokenizer.json / vocab.txt under {directory}")
+            lower = True
+            cfg = os.path.join(directory, 'tokenizer_config.json')
+            if os.path.exists(cfg):
+                with open(cfg, 'r', encoding='utf-8') as f:
+                    lower = json.load(f).get('do_lower_case', True)
+            self.tok = BertWordPieceTokenizer(vocab, lowercase=lower)
+        self.cls_id = self.tok.token_to_id('[CLS]')
+        self.sep_id = self.tok.token_to_id('[SEP]')
+        self.pad_id = self.tok.token_to_id('[PAD]') or 0
+
+    def encode(self, text):
+        return self.tok.encode(text, add_special_tokens=False).ids
+
+
+def _resolve_dir(spec):
+    if os.path.isdir(spec):
+        return spec
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(spec, local_files_only=True)
+    except Exception as e:
+        raise FileNotFoundError(
+            f"model {spec!r} is not a local directory and is not in the local Hugging Face cache "
+            f"({type(e).__name__}); pass a directory or a 'random:<arch>' spec") from e
+
+
+def load_model(spec, kind, device, dtype=torch.float32, seed=0):
+    """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config)."""
+    cls = BiEncoder if kind == 'bi' else CrossEncoderModel
+    if spec.startswith('random:'):
+        arch = spec.split(':', 1)[1]
+        if arch not in ARCHS:
+            raise ValueError(f"unknown random architecture {arch!r}; known: {sorted(ARCHS)}")
+        cfg = ARCHS[arch]
+        model = cls(cfg)
+        gen = torch.Generator().manual_seed(seed + (0 if kind == 'bi' else 1))
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if name.endswith('norm.weight'):
+                    p.fill_(1.0)
+                elif name.endswith('bias'):
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+        tok = HashTokenizer(cfg.vocab_size)
+    else:
+        directory = _resolve_dir(spec)
+        cfg = BertConfig.from_json(os.path.join(directory, 'config.json'))
+        model = cls(cfg)
+        state = _convert_hf_state(_read_weights(directory), cfg.num_hidden_layers)
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        bad = [m for m in missing if not (kind == 'bi' and m.startswith(('pooler', 'classifier')))]
+        if bad:
+            raise RuntimeError(f"checkpoint under {directory} lacks weights: {bad[:5]}")
+        tok = FileTokenizer(directory)
+    model.eval().to(device=device, dtype=dtype)
+    return model, tok, cfg
+
+
+def pad_batch(seqs, pad_id, device):
+    """list of id lists -> (ids, mask) int64 tensors padded to the longest."""
+    n = max((len(s) for s in seqs), default=0)
+    n = max(n, 1)
+    ids = torch.full((len(seqs), n), pad_id, dtype=torch.int64)
+    mask = torch.zeros((len(seqs), n), dtype=torch.int64)
+    for i, s in enumerate(seqs):
+        ids[i, :len(s)] = torch.tensor(s, dtype=torch.int64)
+        mask[i, :len(s)] = 1
+    return ids.to(device), mask.to(device)

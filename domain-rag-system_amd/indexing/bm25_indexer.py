@@ -1,0 +1,247 @@
+"""BM25 retriever backed by the HIP postings kernels.
+
+Drop-in for the reference ``BM25Indexer`` (reference ``src/indexing/bm25_indexer.py:20-213``):
+same constructor, ``tokenize`` / ``index_chunks`` / ``search`` / ``save`` / ``load`` /
+``get_stats`` and the same result dicts.  What differs is underneath: instead of a
+``rank_bm25.BM25Okapi`` object holding one dict per document, the index is a term-major CSR
+(``indptr``, ``rows``, fp64 ``impact``) plus ``idf``, resident in HBM, and ``search`` runs
+``rag_bm25_search`` (no CPU scoring path exists; a missing library or GPU raises).
+
+Arithmetic contract (rank_bm25 0.2.x ``BM25Okapi``, restated):
+    idf(t)   = ln(N - df + 0.5) - ln(df + 0.5); negative values become 0.25 * mean idf
+    impact   = tf*(k1+1) / (tf + k1*(1 - b + b*doc_len/avgdl))
+    score(d) = sum over query tokens, in query order, of idf(t) * impact(t, d)     (fp64)
+Ranking: score descending, equal scores by row index descending (the order a stable
+``argsort`` followed by ``[::-1]`` produces; upstream's order among ties is unspecified).
+"""
+import math
+import pickle
+import re
+from pathlib import Path
+
+import numpy as np
+
+try:                                    # both import spellings of the reference tree work
+    from preprocessing import MedicalTermNormalizer
+except ImportError:                     # pragma: no cover - depends on sys.path layout
+    from ..preprocessing import MedicalTermNormalizer
+
+import rag_hip
+
+_TOKEN = re.compile(r'\b\w+\b')
+_EPSILON = 0.25
+
+
+class Bm25Arrays:
+    """Host-side image of the device index (what save/load persist)."""
+
+    def __init__(self, vocab, indptr, rows, tf, idf, doc_len, avgdl, k1, b):
+        self.vocab, self.indptr, self.rows, self.tf = vocab, indptr, rows, tf
+        self.idf, self.doc_len, self.avgdl, self.k1, self.b = idf, doc_len, avgdl, k1, b
+
+    @property
+    def n_docs(self):
+        return int(self.doc_len.shape[0])
+
+    def impacts(self):
+        """tf*(k1+1) / (tf + k1*(1 - b + b*doc_len/avgdl)), evaluated in the operand order of
+        the upstream expression so every posting's value is bit-identical to it."""
+        k1, b = self.k1, self.b
+        norm = k1 * (1 - b + b * self.doc_len / self.avgdl)
+        tf = self.tf.astype(np.int64)
+        return tf * (k1 + 1) / (tf + norm[self.rows])
+
+
+def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b):
+    """Flat token occurrences (term id, doc id) -> CSR + statistics."""
+    n_docs = int(doc_len.shape[0])
+    v = len(vocab) if not isinstance(vocab, int) else vocab
+    if n_docs == 0:
+        raise ValueError("cannot build a BM25 index over zero documents")
+    key = term_ids.astype(np.int64) * n_docs + doc_ids.astype(np.int64)
+    uniq, tf = np.unique(key, return_counts=True)
+    post_term = uniq // n_docs
+    rows = (uniq - post_term * n_docs).astype(np.uint32)
+    df = np.bincount(post_term, minlength=v).astype(np.int64)
+    indptr = np.zeros(v + 1, np.int64)
+    np.cumsum(df, out=indptr[1:])
+    # idf with libm's log, summed in vocabulary (first appearance) order
+    idf = np.zeros(v, np.float64)
+    total = 0
+    log = math.log
+    for t in range(v):
+        n_t = int(df[t])
+        if n_t:
+            val = log(n_docs - n_t + 0.5) - log(n_t + 0.5)
+            idf[t] = val
+            total += val
+    present = int(np.count_nonzero(df))
+    if present:
+        floor = _EPSILON * (total / present)
+        idf[(idf < 0) & (df > 0)] = floor
+    avgdl = int(doc_len.sum()) / n_docs
+    return Bm25Arrays(vocab, indptr, rows, tf.astype(np.uint32), idf, doc_len.astype(np.int64), avgdl, k1, b)
+
+
+class BM25Indexer:
+    def __init__(self, k1: float = 1.5, b: float = 0.75, medical_normalizer: MedicalTermNormalizer = None):
+        rag_hip.load_library()              # fail at construction when the backend is missing
+        self.k1 = k1
+        self.b = b
+        self.normalizer = medical_normalizer or MedicalTermNormalizer()
+        self.bm25 = None                    # Bm25Arrays once built (name kept for callers)
+        self.chunks = []
+        self.tokenized_corpus = []
+        self._device_index = None
+        self._short_keys = None
+
+    # ---- tokenizer -------------------------------------------------------------------
+    def tokenize(self, text: str):
+        """Lower-case word tokens of at least two characters; a one-character token survives
+        only when it equals a lower-cased abbreviation key occurring in the text."""
+        low = text.lower()
+        tokens = _TOKEN.findall(low)
+        if self._short_keys is None:
+            self._short_keys = [k.lower() for k in self.normalizer.abbreviations.keys() if len(k.lower()) < 2]
+        if not self._short_keys:            # no abbreviation key can rescue a short token
+            return [t for t in tokens if len(t) >= 2]
+        rescued = {k for k in self._short_keys if k in low}
+        return [t for t in tokens if len(t) >= 2 or t in rescued]
+
+    # ---- build -----------------------------------------------------------------------
+    @staticmethod
+    def _text_of(chunk):
+        return chunk.text if hasattr(chunk, 'text') else chunk['text']
+
+    def index_chunks(self, chunks):
+        """Tokenise every chunk and build the device index.  Rebuilds from scratch on every
+        call (the reference appends to its token lists and corrupts a second build)."""
+        self.chunks = chunks
+        self.tokenized_corpus = [self.tokenize(self._text_of(c)) for c in chunks]
+        self._build(self.tokenized_corpus)
+
+    def _build(self, tokenized):
+        vocab = {}
+        n_tokens = sum(len(d) for d in tokenized)
+        term_ids = np.empty(n_tokens, np.int64)
+        doc_ids = np.empty(n_tokens, np.int64)
+        doc_len = np.empty(len(tokenized), np.int64)
+        at = 0
+        for d, doc in enumerate(tokenized):
+            doc_len[d] = len(doc)
+            for w in doc:
+                t = vocab.get(w)
+                if t is None:
+                    t = len(vocab)
+                    vocab[w] = t
+                term_ids[at] = t
+                doc_ids[at] = d
+                at += 1
+        self.bm25 = build_arrays(term_ids, doc_ids, doc_len, vocab, self.k1, self.b)
+        self._upload()
+
+    def _upload(self):
+        a = self.bm25
+        if self._device_index is not None:
+            self._device_index.close()
+        self._device_index = rag_hip.Bm25Index(a.indptr, a.rows, a.impacts(), a.idf, a.n_docs)
+
+    # ---- search ----------------------------------------------------------------------
+    def term_ids(self, tokens):
+        vocab = self.bm25.vocab
+        return [vocab.get(t, -1) for t in tokens]
+
+    def search_rows(self, queries, k):
+        """Batched core: list of query strings -> (scores [B,k] f64, rows [B,k], counts)."""
+        if self.bm25 is None:
+            raise ValueError("Index not built. Call index_chunks() first.")
+        ids = [self.term_ids(self.tokenize(q)) for q in queries]
+        k = min(int(k), rag_hip.MAX_K)
+        return self._device_index.search(ids, k)
+
+    def _format(self, idx, score):
+        c = self.chunks[idx]
+        d = c.to_dict() if hasattr(c, 'to_dict') else c
+        return {
+            'chunk_id': d.get('chunk_id', f'chunk_{idx}'),
+            'doc_id': d.get('doc_id', ''),
+            'source': d.get('source', ''),
+            'chunk_type': d.get('chunk_type', ''),
+            'text': d.get('text', ''),
+            'metadata': d.get('metadata', {}),
+            'score': score,
+        }
+
+    def search(self, query: str, top_k: int = 10, filters: dict = None):
+        """Best ``top_k`` chunks out of a ``2*top_k`` candidate window; ``filters`` are
+        equality tests on top-level chunk keys applied inside that window, so fewer than
+        ``top_k`` results can come back (reference ``bm25_indexer.py:128-161``)."""
+        if self.bm25 is None:
+            raise ValueError("Index not built. Call index_chunks() first.")
+        if top_k <= 0:
+            return []
+        window = top_k * 2 if filters else top_k
+        score, row, cnt = self.search_rows([query], min(window, max(len(self.chunks), 1)))
+        out = []
+        for j in range(int(cnt[0])):
+            idx = int(row[0, j])
+            r = self._format(idx, float(score[0, j]))
+            if filters:
+                c = self.chunks[idx]
+                d = c.to_dict() if hasattr(c, 'to_dict') else c
+                if any(d.get(key) != val for key, val in filters.items()):
+                    continue
+            out.append(r)
+            if len(out) >= top_k:
+                break
+        return out
+
+    # ---- persistence -----------------------------------------------------------------
+    def save(self, filepath: str):
+        """``bm25_index.pkl``: a pickle of a plain dict with the reference's five keys
+        (``bm25``, ``chunks``, ``tokenized_corpus``, ``k1``, ``b``).  ``bm25`` holds plain
+        numpy arrays / builtins instead of a ``rank_bm25`` instance."""
+        filepath = Path(filepath)
+        filepath.parent.mkdir(parents=True, exist_ok=True)
+        a = self.bm25
+        state = None if a is None else {
+            'format': 'rag_hip.bm25.v1', 'vocab': a.vocab, 'indptr': a.indptr, 'rows': a.rows, 'tf': a.tf,
+            'idf': a.idf, 'doc_len': a.doc_len, 'avgdl': a.avgdl, 'k1': a.k1, 'b': a.b, 'epsilon': _EPSILON,
+            'corpus_size': a.n_docs}
+        chunks = [c.to_dict() if hasattr(c, 'to_dict') else c for c in self.chunks]
+        with open(filepath, 'wb') as f:
+            pickle.dump({'bm25': state, 'chunks': chunks, 'tokenized_corpus': self.tokenized_corpus,
+                         'k1': self.k1, 'b': self.b}, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def load(self, filepath: str):
+        filepath = Path(filepath)
+        if not filepath.exists():
+            raise FileNotFoundError(f"Index file not found: {filepath}")
+        with open(filepath, 'rb') as f:
+            data = pickle.load(f)           # a file this class wrote
+        self.chunks = data['chunks']
+        self.tokenized_corpus = data['tokenized_corpus']
+        self.k1 = data['k1']
+        self.b = data['b']
+        s = data['bm25']
+        if isinstance(s, dict) and s.get('format') == 'rag_hip.bm25.v1':
+            self.bm25 = Bm25Arrays(s['vocab'], s['indptr'], s['rows'], s['tf'], s['idf'], s['doc_len'],
+                                   s['avgdl'], s['k1'], s['b'])
+            self._upload()
+        elif self.tokenized_corpus:
+            # a pickle from another writer: rebuild from its token lists
+            self._build(self.tokenized_corpus)
+        else:
+            self.bm25 = None
+
+    def get_stats(self):
+        if self.bm25 is None:
+            return {'error': 'Index not built'}
+        a = self.bm25
+        return {
+            'num_documents': len(self.chunks),
+            'avg_doc_length': float(np.mean(a.doc_len)) if a.n_docs else 0.0,
+            'vocab_size': int(np.count_nonzero(np.diff(a.indptr))),
+            'k1': self.k1,
+            'b': self.b,
+        }

@@ -1,0 +1,436 @@
+"""ctypes binding of ``librag_hip.so`` (declared in ``include/rag_hip.h``).
+
+The library is the only compute backend of this package: when it is missing, or no
+gfx950 GPU is usable, the entry points raise.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librag_hip.so')
+
+METRIC_COSINE, METRIC_DOT, METRIC_EUCLID = 0, 1, 2
+MEM_HOST_COPY, MEM_DEVICE_COPY, MEM_DEVICE_BORROW = 0, 1, 2
+MAX_K = 1024
+MAX_FUSE_LIST = 512
+
+_METRICS = {'cosine': METRIC_COSINE, 'dot': METRIC_DOT, 'euclidean': METRIC_EUCLID, 'euclid': METRIC_EUCLID}
+
+
+class RagHipError(RuntimeError):
+    pass
+
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); every symbol of include/rag_hip.h
+SIGNATURES = {
+    'rag_init': (_i32, [_i32]),
+    'rag_last_error': (C.c_char_p, []),
+    'rag_version': (_i32, []),
+    'rag_dense_create': (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
+    'rag_dense_destroy': (_i32, [_vp]),
+    'rag_dense_rows': (_i64, [_vp]),
+    'rag_dense_search_dev': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'rag_dense_search': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'rag_dense_rescore_dev': (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    'rag_dense_rescore': (_i32, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    'rag_bm25_create': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, C.POINTER(_vp)]),
+    'rag_bm25_destroy': (_i32, [_vp]),
+    'rag_bm25_docs': (_i64, [_vp]),
+    'rag_bm25_search_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'rag_bm25_search': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'rag_bm25_scores': (_i32, [_vp, _vp, _i32, _vp]),
+    'rag_merge_topk_f32_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'rag_merge_topk_f64_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'rag_fuse_rrf_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
+    'rag_fuse_weighted_dev': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f64, _f64,
+                                     _vp, _vp, _vp, _vp, _vp]),
+    'rag_fuse_rrf': (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
+    'rag_fuse_weighted': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _f64,
+                                 _vp, _vp, _vp, _vp]),
+    'rag_topk_segmented_dev': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'rag_topk_segmented': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    'rag_ce_pack_dev': (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                               _vp, _vp, _vp, _vp]),
+    'rag_ce_pair_len_dev': (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_inited_devices = set()
+
+
+def load_library():
+    """dlopen the library and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RagHipError(
+                    f"{LIB_PATH} is missing: build it with `make -C domain-rag-system_amd/csrc` "
+                    "(or __graft_entry__.build()); this package has no CPU fallback")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    return load_library().rag_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RagHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def init(device=0):
+    """Bind the calling thread to `device` and verify it is a gfx950 part."""
+    lib = load_library()
+    check(lib.rag_init(int(device)), 'rag_init')
+    _inited_devices.add(int(device))
+    return lib
+
+
+def lib():
+    l = load_library()
+    if not _inited_devices:
+        init(0)
+    return l
+
+
+def metric_code(name):
+    try:
+        return _METRICS[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"unknown distance metric {name!r}")
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("device tensors passed to rag_hip must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------
+class DenseIndex:
+    """Resident [N x D] fp32 matrix with exact top-k search (rag_dense_* entry points)."""
+
+    def __init__(self, rows, metric='cosine', row_base=0, borrow=False):
+        l = lib()
+        self.metric = metric_code(metric)
+        self._keep = None
+        h = _vp()
+        if hasattr(rows, 'data_ptr'):            # torch tensor on the GPU
+            import torch
+            if rows.dtype != torch.float32 or rows.dim() != 2 or not rows.is_cuda:
+                raise ValueError("device rows must be a 2-d float32 CUDA tensor")
+            rows = rows.contiguous()
+            n, d = rows.shape
+            kind = MEM_DEVICE_BORROW if borrow else MEM_DEVICE_COPY
+            if borrow:
+                self._keep = rows
+            torch.cuda.synchronize()
+            check(l.rag_dense_create(rows.data_ptr(), n, d, self.metric, kind, int(row_base), C.byref(h)),
+                  'rag_dense_create')
+        else:
+            arr, p = _np(rows, np.float32)
+            if arr.ndim != 2:
+                raise ValueError("rows must be 2-d")
+            n, d = arr.shape
+            check(l.rag_dense_create(p, n, d, self.metric, MEM_HOST_COPY, int(row_base), C.byref(h)),
+                  'rag_dense_create')
+        self.n_rows, self.dim, self.row_base = int(n), int(d), int(row_base)
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load_library().rag_dense_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def search(self, queries, k, row_mask=None):
+        """Host arrays in, host arrays out: (scores [B,k] f32, rows [B,k] i64, counts [B] i32)."""
+        q, qp = _np(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"query dim {q.shape[1]} != index dim {self.dim}")
+        b = q.shape[0]
+        score = np.zeros((b, k), np.float32)
+        row = np.full((b, k), -1, np.int64)
+        cnt = np.zeros(b, np.int32)
+        mp = None
+        if row_mask is not None:
+            m, mp = _np(row_mask, np.uint8)
+            if m.shape != (self.n_rows,):
+                raise ValueError("row_mask must have one byte per local row")
+        check(lib().rag_dense_search(self._h, q.ctypes.data, b, int(k), mp, score.ctypes.data, row.ctypes.data,
+                                     cnt.ctypes.data), 'rag_dense_search')
+        return score, row, cnt
+
+    def search_dev(self, queries, k, row_mask=None, out=None):
+        """torch CUDA tensors in/out, asynchronous on the current stream."""
+        import torch
+        b = queries.shape[0]
+        if queries.dtype != torch.float32 or queries.shape[1] != self.dim:
+            raise ValueError("queries must be float32 [B, dim]")
+        if out is None:
+            out = (torch.empty((b, k), dtype=torch.float32, device=queries.device),
+                   torch.empty((b, k), dtype=torch.int64, device=queries.device),
+                   torch.empty((b,), dtype=torch.int32, device=queries.device))
+        score, row, cnt = out
+        check(lib().rag_dense_search_dev(self._h, _ptr(queries), b, int(k), _ptr(row_mask), _ptr(score), _ptr(row),
+                                         _ptr(cnt), _stream()), 'rag_dense_search_dev')
+        return score, row, cnt
+
+    def rescore(self, queries, cand_rows):
+        q, _ = _np(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        c, _ = _np(cand_rows, np.int64)
+        c = c.reshape(q.shape[0], -1)
+        out = np.zeros(c.shape, np.float32)
+        check(lib().rag_dense_rescore(self._h, q.ctypes.data, q.shape[0], c.ctypes.data, c.shape[1], out.ctypes.data),
+              'rag_dense_rescore')
+        return out
+
+    def rescore_dev(self, queries, cand_rows):
+        import torch
+        b, m = cand_rows.shape
+        out = torch.empty((b, m), dtype=torch.float32, device=queries.device)
+        check(lib().rag_dense_rescore_dev(self._h, _ptr(queries), b, _ptr(cand_rows), m, _ptr(out), _stream()),
+              'rag_dense_rescore_dev')
+        return out
+
+
+class Bm25Index:
+    """Term-major CSR postings with fp64 impacts (rag_bm25_* entry points)."""
+
+    def __init__(self, indptr, rows, impact, idf, n_docs, row_base=0):
+        l = lib()
+        self._arrays = [np.ascontiguousarray(indptr, np.int64), np.ascontiguousarray(rows, np.uint32),
+                        np.ascontiguousarray(impact, np.float64), np.ascontiguousarray(idf, np.float64)]
+        ip, rw, im, df = self._arrays
+        vocab = ip.shape[0] - 1
+        if df.shape[0] != vocab or rw.shape[0] != im.shape[0] or (vocab >= 0 and ip[-1] != rw.shape[0]):
+            raise ValueError("inconsistent CSR arrays")
+        h = _vp()
+        check(l.rag_bm25_create(ip.ctypes.data, rw.ctypes.data, im.ctypes.data, df.ctypes.data, int(n_docs), int(vocab),
+                                MEM_HOST_COPY, int(row_base), C.byref(h)), 'rag_bm25_create')
+        self._arrays = None
+        self._h = h
+        self.n_docs, self.vocab, self.row_base = int(n_docs), int(vocab), int(row_base)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load_library().rag_bm25_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def flatten(queries):
+        """list of term-id lists -> (qterms int32, qoff int32)."""
+        off = np.zeros(len(queries) + 1, np.int32)
+        for i, q in enumerate(queries):
+            off[i + 1] = off[i] + len(q)
+        terms = np.zeros(int(off[-1]), np.int32)
+        for i, q in enumerate(queries):
+            terms[off[i]:off[i + 1]] = q
+        return terms, off
+
+    def search(self, queries, k):
+        terms, off = self.flatten(queries)
+        b = len(queries)
+        score = np.zeros((b, k), np.float64)
+        row = np.full((b, k), -1, np.int64)
+        cnt = np.zeros(b, np.int32)
+        check(lib().rag_bm25_search(self._h, terms.ctypes.data, off.ctypes.data, b, int(k), score.ctypes.data,
+                                    row.ctypes.data, cnt.ctypes.data), 'rag_bm25_search')
+        return score, row, cnt
+
+    def search_dev(self, qterms, qoff, n_terms_total, k, out=None):
+        import torch
+        b = qoff.shape[0] - 1
+        if out is None:
+            out = (torch.empty((b, k), dtype=torch.float64, device=qoff.device),
+                   torch.empty((b, k), dtype=torch.int64, device=qoff.device),
+                   torch.empty((b,), dtype=torch.int32, device=qoff.device))
+        score, row, cnt = out
+        check(lib().rag_bm25_search_dev(self._h, _ptr(qterms), _ptr(qoff), b, int(n_terms_total), int(k), _ptr(score),
+                                        _ptr(row), _ptr(cnt), _stream()), 'rag_bm25_search_dev')
+        return score, row, cnt
+
+    def scores(self, query_terms):
+        t = np.ascontiguousarray(query_terms, np.int32)
+        out = np.zeros(self.n_docs, np.float64)
+        check(lib().rag_bm25_scores(self._h, t.ctypes.data, int(t.shape[0]), out.ctypes.data), 'rag_bm25_scores')
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+def _pad_lists(lists, dtype, fill):
+    b = len(lists)
+    stride = max([len(x) for x in lists] + [0])
+    arr = np.full((b, max(stride, 1)), fill, dtype)
+    cnt = np.zeros(b, np.int32)
+    for i, x in enumerate(lists):
+        arr[i, :len(x)] = x
+        cnt[i] = len(x)
+    return arr, cnt, stride
+
+
+def fuse_rrf(vec_rows, bm_rows, top_k, canon=None, k_const=60.0):
+    """Lists of row-id lists (one per query) -> (pos [B,top_k], row, score f64, count)."""
+    b = len(vec_rows)
+    v, vc, vs = _pad_lists(vec_rows, np.int64, -1)
+    m, mc, ms = _pad_lists(bm_rows, np.int64, -1)
+    pos = np.full((b, top_k), -1, np.int32)
+    row = np.full((b, top_k), -1, np.int64)
+    score = np.zeros((b, top_k), np.float64)
+    cnt = np.zeros(b, np.int32)
+    cp, cn = (None, 0)
+    if canon is not None:
+        canon = np.ascontiguousarray(canon, np.uint32)
+        cp, cn = canon.ctypes.data, canon.shape[0]
+    check(lib().rag_fuse_rrf(v.ctypes.data, vc.ctypes.data, v.shape[1] if vs else 0, m.ctypes.data, mc.ctypes.data,
+                             m.shape[1] if ms else 0, cp, cn, b, int(top_k), float(k_const), pos.ctypes.data,
+                             row.ctypes.data, score.ctypes.data, cnt.ctypes.data), 'rag_fuse_rrf')
+    return pos, row, score, cnt
+
+
+def fuse_weighted(vec_rows, vec_scores, bm_rows, bm_scores, top_k, vector_weight=0.5, bm25_weight=0.5, canon=None):
+    b = len(vec_rows)
+    v, vc, vs = _pad_lists(vec_rows, np.int64, -1)
+    vsc, _, _ = _pad_lists(vec_scores, np.float64, 0)
+    m, mc, ms = _pad_lists(bm_rows, np.int64, -1)
+    msc, _, _ = _pad_lists(bm_scores, np.float64, 0)
+    pos = np.full((b, top_k), -1, np.int32)
+    row = np.full((b, top_k), -1, np.int64)
+    score = np.zeros((b, top_k), np.float64)
+    cnt = np.zeros(b, np.int32)
+    cp, cn = (None, 0)
+    if canon is not None:
+        canon = np.ascontiguousarray(canon, np.uint32)
+        cp, cn = canon.ctypes.data, canon.shape[0]
+    check(lib().rag_fuse_weighted(v.ctypes.data, vsc.ctypes.data, vc.ctypes.data, v.shape[1] if vs else 0,
+                                  m.ctypes.data, msc.ctypes.data, mc.ctypes.data, m.shape[1] if ms else 0, cp, cn, b,
+                                  int(top_k), float(vector_weight), float(bm25_weight), pos.ctypes.data,
+                                  row.ctypes.data, score.ctypes.data, cnt.ctypes.data), 'rag_fuse_weighted')
+    return pos, row, score, cnt
+
+
+def fuse_rrf_dev(vec_row, vec_cnt, bm_row, bm_cnt, top_k, canon=None, k_const=60.0):
+    import torch
+    b = vec_row.shape[0]
+    dev = vec_row.device
+    pos = torch.empty((b, top_k), dtype=torch.int32, device=dev)
+    row = torch.empty((b, top_k), dtype=torch.int64, device=dev)
+    score = torch.empty((b, top_k), dtype=torch.float64, device=dev)
+    cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+    check(lib().rag_fuse_rrf_dev(_ptr(vec_row), _ptr(vec_cnt), vec_row.shape[1], _ptr(bm_row), _ptr(bm_cnt),
+                                 bm_row.shape[1], _ptr(canon), b, int(top_k), float(k_const), _ptr(pos), _ptr(row),
+                                 _ptr(score), _ptr(cnt), _stream()), 'rag_fuse_rrf_dev')
+    return pos, row, score, cnt
+
+
+def fuse_weighted_dev(vec_row, vec_score, vec_cnt, bm_row, bm_score, bm_cnt, top_k, vector_weight=0.5,
+                      bm25_weight=0.5, canon=None):
+    import torch
+    b = vec_row.shape[0]
+    dev = vec_row.device
+    pos = torch.empty((b, top_k), dtype=torch.int32, device=dev)
+    row = torch.empty((b, top_k), dtype=torch.int64, device=dev)
+    score = torch.empty((b, top_k), dtype=torch.float64, device=dev)
+    cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+    check(lib().rag_fuse_weighted_dev(_ptr(vec_row), _ptr(vec_score), _ptr(vec_cnt), vec_row.shape[1], _ptr(bm_row),
+                                      _ptr(bm_score), _ptr(bm_cnt), bm_row.shape[1], _ptr(canon), b, int(top_k),
+                                      float(vector_weight), float(bm25_weight), _ptr(pos), _ptr(row), _ptr(score),
+                                      _ptr(cnt), _stream()), 'rag_fuse_weighted_dev')
+    return pos, row, score, cnt
+
+
+def topk_segmented(scores, seg_off, top_k):
+    s, _ = _np(scores, np.float32)
+    o, _ = _np(seg_off, np.int32)
+    b = o.shape[0] - 1
+    idx = np.full((b, top_k), -1, np.int32)
+    cnt = np.zeros(b, np.int32)
+    check(lib().rag_topk_segmented(s.ctypes.data, o.ctypes.data, b, int(top_k), idx.ctypes.data, cnt.ctypes.data),
+          'rag_topk_segmented')
+    return idx, cnt
+
+
+def topk_segmented_dev(scores, seg_off, top_k):
+    import torch
+    b = seg_off.shape[0] - 1
+    idx = torch.empty((b, top_k), dtype=torch.int32, device=scores.device)
+    cnt = torch.empty((b,), dtype=torch.int32, device=scores.device)
+    check(lib().rag_topk_segmented_dev(_ptr(scores), _ptr(seg_off), b, int(top_k), _ptr(idx), _ptr(cnt), _stream()),
+          'rag_topk_segmented_dev')
+    return idx, cnt
+
+
+def merge_topk_dev(score, row, count, k_out, smaller_is_better=False):
+    """[B, L, k_in] lists (fp32 or fp64 scores, int64 global rows) -> sorted [B, k_out]."""
+    import torch
+    b, nl, kin = score.shape
+    dev = score.device
+    out_s = torch.empty((b, k_out), dtype=score.dtype, device=dev)
+    out_r = torch.empty((b, k_out), dtype=torch.int64, device=dev)
+    out_c = torch.empty((b,), dtype=torch.int32, device=dev)
+    if score.dtype == torch.float32:
+        check(lib().rag_merge_topk_f32_dev(_ptr(score), _ptr(row), _ptr(count), b, nl, kin, int(k_out),
+                                           1 if smaller_is_better else 0, _ptr(out_s), _ptr(out_r), _ptr(out_c),
+                                           _stream()), 'rag_merge_topk_f32_dev')
+    elif score.dtype == torch.float64:
+        check(lib().rag_merge_topk_f64_dev(_ptr(score), _ptr(row), _ptr(count), b, nl, kin, int(k_out), _ptr(out_s),
+                                           _ptr(out_r), _ptr(out_c), _stream()), 'rag_merge_topk_f64_dev')
+    else:
+        raise ValueError("scores must be float32 or float64")
+    return out_s, out_r, out_c
+
+
+def ce_pair_len_dev(query_off, chunk_off, chunk_row_base, pair_query, pair_row, max_len):
+    import torch
+    n = pair_row.shape[0]
+    out = torch.empty((n,), dtype=torch.int32, device=pair_row.device)
+    check(lib().rag_ce_pair_len_dev(_ptr(query_off), _ptr(chunk_off), int(chunk_row_base), _ptr(pair_query),
+                                    _ptr(pair_row), n, int(max_len), _ptr(out), _stream()), 'rag_ce_pair_len_dev')
+    return out
+
+
+def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair_query, pair_row, pair_slot,
+                n_slots, seq_len, cls_id=101, sep_id=102, pad_id=0):
+    import torch
+    dev = pair_row.device
+    ids = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
+    types = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
+    mask = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
+    check(lib().rag_ce_pack_dev(_ptr(query_tok), _ptr(query_off), _ptr(chunk_tok), _ptr(chunk_off),
+                                int(chunk_row_base), _ptr(pair_query), _ptr(pair_row), _ptr(pair_slot),
+                                pair_row.shape[0], int(seq_len), int(cls_id), int(sep_id), int(pad_id), _ptr(ids),
+                                _ptr(types), _ptr(mask), _stream()), 'rag_ce_pack_dev')
+    return ids, types, mask

@@ -1,0 +1,201 @@
+/*
+ * rag_hip.h - C ABI of librag_hip.so, the MI355X (gfx950) retrieval kernels.
+ *
+ * The reference (Luyu-H/Domain-RAG-System) is pure Python and has no FFI of its own;
+ * the seam these entry points sit behind is its Python class API.  Each entry point
+ * names the reference call it replaces.  The Python host classes in
+ * domain-rag-system_amd/ bind this file through ctypes.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative RAG_E* code otherwise;
+ *    rag_last_error() returns a thread-local message for the last failure.
+ *  - handles are opaque pointers; they are immutable after create and may be searched
+ *    from several host threads as long as each call uses its own stream and workspace
+ *    (calls on one handle share that handle's workspace: serialise them or use one
+ *    handle per thread).
+ *  - "_dev" entry points take DEVICE pointers, enqueue on `stream` (a hipStream_t passed
+ *    as void*, NULL = the default stream) and return without synchronising.  They may
+ *    grow the handle's cached workspace (hipMalloc) when a call needs more than any
+ *    earlier one; steady-state calls allocate nothing.
+ *  - entry points without the suffix take HOST pointers, copy in/out and synchronise.
+ *  - rows are reported as GLOBAL row ids: local row + the `row_base` given at create
+ *    (row_base is the first row of this GPU's shard; 0 when unsharded).
+ *  - result lists are ordered best first; ties by row id DESCENDING (the order that
+ *    numpy's stable argsort followed by [::-1] gives; the reference's own order among
+ *    equal scores is implementation defined).  Unused slots hold row -1.
+ */
+#ifndef RAG_HIP_H
+#define RAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAG_OK            0
+#define RAG_EINVAL       -1   /* bad argument                                  */
+#define RAG_EHIP         -2   /* a HIP runtime call failed                     */
+#define RAG_ENOMEM       -3   /* allocation failed                             */
+#define RAG_ENODEV       -4   /* no usable gfx950 device                       */
+#define RAG_ELIMIT       -5   /* argument beyond a documented limit            */
+
+#define RAG_METRIC_COSINE 0   /* rows are expected L2-normalised; score = dot  */
+#define RAG_METRIC_DOT    1
+#define RAG_METRIC_EUCLID 2   /* score = Euclidean distance, smaller is better */
+
+#define RAG_MEM_HOST_COPY   0 /* pointer is host memory, the library copies it */
+#define RAG_MEM_DEVICE_COPY 1 /* pointer is device memory, the library copies  */
+#define RAG_MEM_DEVICE_BORROW 2 /* device memory, caller keeps it alive        */
+
+#define RAG_MAX_K        1024 /* largest k of any top-k entry point            */
+#define RAG_MAX_FUSE_LIST 512 /* entries per input list of the fusion kernels  */
+
+typedef struct rag_dense_s* rag_dense_t;
+typedef struct rag_bm25_s*  rag_bm25_t;
+
+/* ---- library ----------------------------------------------------------------- */
+
+/* Select `device` for the calling thread and check it is a gfx950 part. */
+int rag_init(int device);
+const char* rag_last_error(void);
+int rag_version(void);
+
+/* ---- dense exact kNN ----------------------------------------------------------
+ * Replaces the embedded Qdrant store behind VectorIndexer.index_chunks
+ * (reference src/indexing/vector_indexer.py:105-163: one fp32 vector per chunk,
+ * id = row index) and the brute-force query_points call of VectorIndexer.search
+ * (reference src/indexing/vector_indexer.py:202-209).                             */
+
+/* rows: [n_rows x dim] fp32 row-major; dim must be a multiple of 4.              */
+int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t metric,
+                     int32_t mem_kind, int64_t row_base, rag_dense_t* out);
+int rag_dense_destroy(rag_dense_t h);
+int64_t rag_dense_rows(rag_dense_t h);
+
+/* queries [n_queries x dim] fp32 (already normalised for cosine).  row_mask: NULL or
+ * one byte per LOCAL row, 0 = excluded (the payload filter of
+ * vector_indexer.py:185-196).  Outputs [n_queries x k]; out_count[q] = entries valid. */
+int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32_t n_queries, int32_t k,
+                         const uint8_t* d_row_mask, float* d_out_score, int64_t* d_out_row,
+                         int32_t* d_out_count, void* stream);
+int rag_dense_search(rag_dense_t h, const float* queries, int32_t n_queries, int32_t k,
+                     const uint8_t* row_mask, float* out_score, int64_t* out_row,
+                     int32_t* out_count);
+
+/* Exact fp32 scores of given candidate rows (GLOBAL ids, -1 = skip -> score 0):
+ * out[q*m+j] = score(query q, row cand[q*m+j]).  Serves SimpleSimilarityReranker
+ * (reference src/reranker/rerank.py:60-68) from the resident embeddings.          */
+int rag_dense_rescore_dev(rag_dense_t h, const float* d_queries, int32_t n_queries,
+                          const int64_t* d_cand_rows, int32_t m, float* d_out_score, void* stream);
+int rag_dense_rescore(rag_dense_t h, const float* queries, int32_t n_queries,
+                      const int64_t* cand_rows, int32_t m, float* out_score);
+
+/* ---- BM25 ---------------------------------------------------------------------
+ * Replaces rank_bm25.BM25Okapi.get_scores + np.argsort behind BM25Indexer.search
+ * (reference src/indexing/bm25_indexer.py:127-128).  The index is term-major CSR:
+ * indptr[vocab+1], rows[nnz] ascending inside a term, impact[nnz] fp64 where
+ * impact = tf*(k1+1) / (tf + k1*(1 - b + b*doc_len/avgdl)), and idf[vocab] fp64
+ * (epsilon floor already applied).  score(doc) = sum over query tokens, in query
+ * order, of idf[t]*impact(t,doc), accumulated in fp64 without contraction.         */
+int rag_bm25_create(const int64_t* indptr, const uint32_t* rows, const double* impact,
+                    const double* idf, int64_t n_docs, int64_t vocab, int32_t mem_kind,
+                    int64_t row_base, rag_bm25_t* out);
+int rag_bm25_destroy(rag_bm25_t h);
+int64_t rag_bm25_docs(rag_bm25_t h);
+
+/* qterms: term ids of all queries back to back (-1 = out of vocabulary, ignored);
+ * qoff[n_queries+1] delimits each query.  Returns the k best documents per query,
+ * zero-score documents included when fewer than k documents match (as the
+ * reference's argsort window does).                                               */
+int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff,
+                        int32_t n_queries, int32_t n_terms_total, int32_t k,
+                        double* d_out_score, int64_t* d_out_row, int32_t* d_out_count, void* stream);
+int rag_bm25_search(rag_bm25_t h, const int32_t* qterms, const int32_t* qoff, int32_t n_queries,
+                    int32_t k, double* out_score, int64_t* out_row, int32_t* out_count);
+/* Dense fp64 score vector of ONE query over all local documents (get_scores itself);
+ * out_scores[n_docs] is host memory.  For parity checks and small corpora.         */
+int rag_bm25_scores(rag_bm25_t h, const int32_t* qterms, int32_t n_terms, double* out_scores);
+
+/* ---- top-k merge (multi-GPU shard merge) -----------------------------------------
+ * Merges per-shard best-first lists gathered from all GPUs into one top-k_out list per
+ * query with the same ordering rule.  Inputs [n_queries x n_lists x k_in]; counts
+ * [n_queries x n_lists] or NULL (then rows < 0 mark unused slots).                 */
+int rag_merge_topk_f32_dev(const float* d_score, const int64_t* d_row, const int32_t* d_count,
+                           int32_t n_queries, int32_t n_lists, int32_t k_in, int32_t k_out,
+                           int32_t smaller_is_better, float* d_out_score, int64_t* d_out_row,
+                           int32_t* d_out_count, void* stream);
+int rag_merge_topk_f64_dev(const double* d_score, const int64_t* d_row, const int32_t* d_count,
+                           int32_t n_queries, int32_t n_lists, int32_t k_in, int32_t k_out,
+                           double* d_out_score, int64_t* d_out_row, int32_t* d_out_count,
+                           void* stream);
+
+/* ---- rank fusion ---------------------------------------------------------------
+ * Replaces HybridIndexer._reciprocal_rank_fusion (reference
+ * src/indexing/hybrid_indexer.py:112-156) and _weighted_fusion (:158-218).
+ * Per query: a vector list (rows [n_queries x vec_stride], vec_count[q] valid) and a
+ * BM25 list.  canon: NULL, or canon[global row] = the first global row that carries the
+ * same chunk_id (the reference fuses on the chunk_id string, which need not be unique).
+ * Scores of both lists are fp64 (widen fp32 dense scores exactly before the call).
+ * Outputs [n_queries x top_k]: out_pos = position of the payload-supplying entry in the
+ * concatenation vector-list + BM25-list, out_row = its global row, out_score fp64.   */
+int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_count, int32_t vec_stride,
+                     const int64_t* d_bm_row, const int32_t* d_bm_count, int32_t bm_stride,
+                     const uint32_t* d_canon, int32_t n_queries, int32_t top_k, double k_const,
+                     int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
+                     int32_t* d_out_count, void* stream);
+int rag_fuse_weighted_dev(const int64_t* d_vec_row, const double* d_vec_score,
+                          const int32_t* d_vec_count, int32_t vec_stride,
+                          const int64_t* d_bm_row, const double* d_bm_score,
+                          const int32_t* d_bm_count, int32_t bm_stride,
+                          const uint32_t* d_canon, int32_t n_queries, int32_t top_k,
+                          double vector_weight, double bm25_weight,
+                          int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
+                          int32_t* d_out_count, void* stream);
+/* host-pointer forms (canon is host memory of n_canon entries, or NULL) */
+int rag_fuse_rrf(const int64_t* vec_row, const int32_t* vec_count, int32_t vec_stride,
+                 const int64_t* bm_row, const int32_t* bm_count, int32_t bm_stride,
+                 const uint32_t* canon, int64_t n_canon, int32_t n_queries, int32_t top_k,
+                 double k_const, int32_t* out_pos, int64_t* out_row, double* out_score,
+                 int32_t* out_count);
+int rag_fuse_weighted(const int64_t* vec_row, const double* vec_score, const int32_t* vec_count,
+                      int32_t vec_stride, const int64_t* bm_row, const double* bm_score,
+                      const int32_t* bm_count, int32_t bm_stride, const uint32_t* canon,
+                      int64_t n_canon, int32_t n_queries, int32_t top_k, double vector_weight,
+                      double bm25_weight, int32_t* out_pos, int64_t* out_row, double* out_score,
+                      int32_t* out_count);
+
+/* ---- rerank ---------------------------------------------------------------------
+ * Replaces the stable descending sort + cut of BaseReranker.rerank (reference
+ * src/reranker/rerank.py:42-43) for a batch of pools: scores of pool q are
+ * d_score[seg_off[q] .. seg_off[q+1]); out_idx [n_queries x top_k] holds positions
+ * inside the pool, best first, ties in pool order.                                 */
+int rag_topk_segmented_dev(const float* d_score, const int32_t* d_seg_off, int32_t n_queries,
+                           int32_t top_k, int32_t* d_out_idx, int32_t* d_out_count, void* stream);
+int rag_topk_segmented(const float* score, const int32_t* seg_off, int32_t n_queries,
+                       int32_t top_k, int32_t* out_idx, int32_t* out_count);
+
+/* Cross-encoder candidate batching: builds the padded token batch that
+ * CrossEncoder.predict builds on the host (reference src/reranker/rerank.py:79-84):
+ * pair p = (query pair_query[p], chunk row pair_row[p]) becomes
+ * [CLS] query tokens [SEP] chunk tokens [SEP], the chunk part truncated so the pair
+ * fits seq_len, written to row pair_slot[p] of the [n_slots x seq_len] outputs
+ * (input ids, token type ids, attention mask), the rest padded with pad_id/0/0.
+ * Token stores are CSR: tok[off[i] .. off[i+1]).  pair_row < 0 yields an all-pad row. */
+int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off,
+                    const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t chunk_row_base,
+                    const int32_t* d_pair_query, const int64_t* d_pair_row,
+                    const int32_t* d_pair_slot, int32_t n_pairs, int32_t seq_len,
+                    int32_t cls_id, int32_t sep_id, int32_t pad_id,
+                    int64_t* d_input_ids, int64_t* d_token_type_ids, int64_t* d_attention_mask,
+                    void* stream);
+/* Length of each pair as rag_ce_pack_dev would write it (before padding, capped at
+ * max_len); used to sort pairs into length buckets.                                */
+int rag_ce_pair_len_dev(const int64_t* d_query_off, const int64_t* d_chunk_off, int64_t chunk_row_base,
+                        const int32_t* d_pair_query, const int64_t* d_pair_row, int32_t n_pairs,
+                        int32_t max_len, int32_t* d_out_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_HIP_H */
