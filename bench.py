@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the hybrid retrieval path on MI355X.
+
+One step = one batch of synthetic queries through
+embed -> dense kNN -> BM25 -> RRF -> cross-encoder rerank -> top-k, everything resident
+in HBM when the timed region starts.  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 the corpus rows are sharded (each rank holds --rows rows: weak scaling in corpus
+size), per-shard top-k lists are all-gathered over RCCL and merged, and the cross-encoder
+pairs are split across the ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'domain-rag-system_amd'))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=1024, help='queries per step')
+    ap.add_argument('--rows', type=int, default=1_000_000, help='corpus rows per GPU')
+    ap.add_argument('--dim', type=int, default=768)
+    ap.add_argument('--vocab', type=int, default=200_000)
+    ap.add_argument('--top-k', type=int, default=5)
+    ap.add_argument('--rerank-top-n', type=int, default=50)
+    ap.add_argument('--ce-dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--embed-arch', default='bert-base')
+    ap.add_argument('--ce-arch', default='minilm-l6')
+    ap.add_argument('--cpu-queries', type=int, default=4, help='queries timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--stage-times', action='store_true', help='extra untimed pass with per-stage events')
+    return ap.parse_args()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_shard(args, rank, world, dev, dist):
+    """Synthetic shard of `args.rows` rows: embeddings, postings, chunk tokens, canon."""
+    import rag_hip
+    from indexing.bm25_indexer import build_arrays
+    from tests import synth
+    n, dim, v = args.rows, args.dim, args.vocab
+    row_base = rank * n
+    t0 = time.time()
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    step = 1 << 18
+    for s in range(0, n, step):
+        blk = torch.randn((min(step, n - s), dim), generator=g, device=dev, dtype=torch.float32)
+        rows[s:s + step] = torch.nn.functional.normalize(blk, dim=1)
+    dense = rag_hip.DenseIndex(rows, metric='cosine', row_base=row_base, borrow=True)
+    log(f'[rank {rank}] dense shard {n}x{dim} in {time.time() - t0:.1f}s')
+
+    t0 = time.time()
+    term, doc, ln = synth.sparse_corpus(n, v, seed=2000 + rank)
+    stats = None
+    if world > 1:
+        df = np.bincount(np.unique(term * n + doc) // n, minlength=v).astype(np.int64)
+        tdf = torch.from_numpy(df).to(dev)
+        tot = torch.tensor([int(ln.sum()), n], dtype=torch.int64, device=dev)
+        dist.all_reduce(tdf)
+        dist.all_reduce(tot)
+        stats = dict(df=tdf.cpu().numpy(), total_len=int(tot[0]), n_docs=int(tot[1]))
+    arr = build_arrays(term, doc, ln, v, 1.5, 0.75, global_stats=stats)
+    bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n, row_base=row_base)
+    log(f'[rank {rank}] bm25 shard: {arr.rows.shape[0]} postings in {time.time() - t0:.1f}s')
+
+    # chunk tokens for the cross-encoder: doc length + 2 synthetic ids per chunk
+    clen = torch.from_numpy(ln + 2).to(dev)
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(clen, 0)
+    tok = torch.randint(1000, 30522, (int(off[-1]),), generator=g, device=dev, dtype=torch.int32)
+    if world > 1:                       # replicate the token store (small) so any rank can pack any pair
+        lens = [torch.empty_like(clen) for _ in range(world)]
+        dist.all_gather(lens, clen)
+        sizes = [int(l.sum()) for l in lens]
+        toks = [torch.empty((s,), dtype=torch.int32, device=dev) for s in sizes]
+        dist.all_gather(toks, tok)
+        tok = torch.cat(toks)
+        clen = torch.cat(lens)
+        off = torch.zeros(n * world + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(clen, 0)
+    # 0.5 % of the rows share a chunk_id with an earlier row (same on every rank)
+    n_all = n * world
+    rng = np.random.default_rng(7)
+    canon = np.arange(n_all, dtype=np.uint32)
+    dup = np.sort(rng.choice(np.arange(1, n_all), size=max(1, n_all // 200), replace=False))
+    for d, u in zip(dup.tolist(), rng.random(dup.shape[0]).tolist()):
+        canon[d] = canon[int(u * d)]    # the canonical row of an earlier row
+    host = dict(term=term, doc=doc, ln=ln, arr=arr, canon=canon)
+    return rows, dense, bm25, tok, off, torch.from_numpy(canon).to(dev), host
+
+
+def make_queries(args, n_batches, dev, seed=99):
+    """Same queries on every rank: embedder token ids, BM25 term ids, cross-encoder token ids."""
+    rng = np.random.default_rng(seed)
+    from tests import synth
+    cdf = np.cumsum(synth.zipf_probs(args.vocab))
+    out = []
+    for _ in range(n_batches):
+        b = args.batch
+        qlen = rng.integers(8, 25, size=b)
+        smax = int(qlen.max()) + 2
+        ids = np.zeros((b, smax), np.int64)
+        mask = np.zeros((b, smax), np.int64)
+        ce_tok, ce_off = [], [0]
+        for i in range(b):
+            body = rng.integers(1000, 30522, size=int(qlen[i]))
+            ids[i, 0], ids[i, 1:1 + qlen[i]], ids[i, 1 + qlen[i]] = 101, body, 102
+            mask[i, :qlen[i] + 2] = 1
+            ce_tok.append(body)
+            ce_off.append(ce_off[-1] + int(qlen[i]))
+        nt = rng.integers(3, 13, size=b)
+        terms = np.minimum(np.searchsorted(cdf, rng.random(int(nt.sum()))), args.vocab - 1).astype(np.int32)
+        oov = rng.random(b) < 0.01
+        qoff = np.zeros(b + 1, np.int32)
+        qoff[1:] = np.cumsum(nt)
+        for i in np.nonzero(oov)[0]:
+            terms[qoff[i]:qoff[i + 1]] = -1
+        out.append(dict(
+            ids=torch.from_numpy(ids).to(dev), mask=torch.from_numpy(mask).to(dev),
+            qterms=torch.from_numpy(terms).to(dev), qoff=torch.from_numpy(qoff).to(dev), n_terms=int(nt.sum()),
+            ce_tok=torch.from_numpy(np.concatenate(ce_tok).astype(np.int32)).to(dev),
+            ce_off=torch.from_numpy(np.asarray(ce_off, np.int64)).to(dev),
+            host=dict(ids=ids, mask=mask, terms=terms, qoff=qoff, ce_tok=ce_tok)))
+    return out
+
+
+def cpu_baseline(args, searcher_models, rows_dev, host, queries, gpu_out):
+    """The oracle (CPU restatement of the reference's algorithms) on a few queries of the same
+    workload, timed on the host cores.  Also compares its ids with the GPU path's."""
+    from oracle.bm25_ref import BM25OkapiArrays, rank_rows_ref
+    from oracle.dense_ref import dense_topk_ref
+    from oracle.fusion_ref import rrf_keys
+    from oracle.rerank_ref import rerank_order_ref
+    from indexing import bert
+    nq = args.cpu_queries
+    cores = os.cpu_count() if os.environ.get('OMP_NUM_THREADS') is None else int(os.environ['OMP_NUM_THREADS'])
+    torch.set_num_threads(cores)
+    bi_cpu, ce_cpu = searcher_models
+    rows = rows_dev.cpu().numpy()
+    t_build = time.time()
+    ref = BM25OkapiArrays.from_token_ids(host['term'], host['doc'], host['ln'], args.vocab)
+    t_build = time.time() - t_build
+    canon = host['canon']
+    q = queries['host']
+    t = args.rerank_top_n
+    k_list = 2 * t
+    agree_fused = agree_final = 0
+    t0 = time.time()
+    for i in range(nq):
+        n_tok = int(q['mask'][i].sum())
+        with torch.no_grad():
+            v = bi_cpu(torch.from_numpy(q['ids'][i:i + 1, :n_tok]), None, torch.from_numpy(q['mask'][i:i + 1, :n_tok]),
+                       normalize=True).numpy()[0]
+        d_rows, _ = dense_topk_ref(rows, v, k_list)
+        terms = q['terms'][q['qoff'][i]:q['qoff'][i + 1]].tolist()
+        s = ref.get_scores_ids(terms)
+        b_rows = rank_rows_ref(s, k_list)
+        fused = rrf_keys([int(canon[r]) for r in d_rows], [int(canon[r]) for r in b_rows], top_k=t)
+        both = list(d_rows) + list(b_rows)
+        f_rows = [int(both[p]) for p, _ in fused]
+        # cross-encoder on the host: pairs of (query tokens, chunk tokens)
+        c_tok = gpu_out['chunk_tokens'](f_rows)
+        qt = list(q['ce_tok'][i])
+        ids_l = [[101] + qt + [102] + c + [102] for c in c_tok]
+        typ_l = [[0] * (len(qt) + 2) + [1] * (len(c) + 1) for c in c_tok]
+        logits = []
+        for s0 in range(0, len(ids_l), 32):
+            ids_t, m_t = bert.pad_batch(ids_l[s0:s0 + 32], 0, 'cpu')
+            ty_t, _ = bert.pad_batch(typ_l[s0:s0 + 32], 0, 'cpu')
+            with torch.no_grad():
+                logits.extend(ce_cpu(ids_t, ty_t, m_t).tolist())
+        order = rerank_order_ref(logits, args.top_k)
+        final = [f_rows[j] for j in order]
+        agree_fused += int(f_rows == gpu_out['fused_row'][i][:len(f_rows)].tolist())
+        agree_final += int(final == gpu_out['rows'][i][:len(final)].tolist())
+    dt = time.time() - t0
+    return {'value': nq / dt, 'unit': 'queries/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{nq} queries of the same workload (full {args.rows}-row corpus), single process, '
+                      f'oracle dense+BM25+RRF in numpy/Python, BERT forwards in PyTorch CPU fp32; '
+                      f'index build ({t_build:.1f}s) not included',
+            'fused_ids_equal_gpu': f'{agree_fused}/{nq}', 'top_k_ids_equal_gpu': f'{agree_final}/{nq}'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    import rag_hip
+    rag_hip.init(local)
+    from indexing import bert
+    from indexing.batch import BatchSearcher, TokenStore
+
+    rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
+    bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev)
+    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev)
+    ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
+    searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
+                             chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
+                             rerank_top_n=args.rerank_top_n, ce_dtype=ce_dtype, dist=dist)
+    n_batches = args.steps + args.warmup
+    queries = make_queries(args, max(n_batches, 1), dev)
+
+    def step(q):
+        return searcher.search(q['ids'], q['mask'], q['qterms'], q['qoff'], q['n_terms'], q['ce_tok'], q['ce_off'])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(queries[i])
+    barrier()
+    dense.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(queries[args.warmup + i])
+    barrier()
+    dt = time.perf_counter() - t0
+    scan_ms = dense.profile_read()
+    dense.profile(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0])
+
+    # per-stage breakdown (untimed extra pass with a sync after every stage)
+    searcher.timing = True
+    step(queries[0])
+    torch.cuda.synchronize()
+    searcher.timing = False
+    stage_ms = {k: round(v, 3) for k, v in searcher.times.as_dict().items()}
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    n_total = args.rows * world
+    t = args.rerank_top_n
+    # dominant hand-written kernel: the dense scan.  Algorithmic work of one launch:
+    #   FLOPs = 2 * rows * dim * batch,  bytes = 4 * rows * dim (one pass over the shard)
+    flops = 2.0 * args.rows * args.dim * args.batch
+    scan_s = float(np.mean(scan_ms)) / 1e3 if len(scan_ms) else float('nan')
+    achieved = flops / scan_s / 1e12
+    roofline = {'kernel': 'dense_scan_kernel', 'bound': 'mfma', 'achieved': round(achieved, 2),
+                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                'traffic': None, 'avg_launch_ms': round(scan_s * 1e3, 3),
+                'algorithmic_gbs': round(4.0 * args.rows * args.dim / scan_s / 1e9, 1)}
+
+    result = {
+        'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
+        'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s (cross-encoder forward) / f32 (embedder forward)' % args.ce_dtype,
+        'data': 'synthetic (seeded random unit vectors, Zipf postings, random token ids, random-init weights)',
+        'config': {'workload': '%dM x %d corpus%s, hybrid vector+BM25, RRF, MiniLM-L6 cross-encoder rerank_top_n=%d, '
+                               'top_k=%d' % (n_total // 1_000_000, args.dim,
+                                             ' row-sharded %d ways' % world if world > 1 else '', t, args.top_k),
+                   'rows_per_gpu': args.rows, 'rows_total': n_total, 'dim': args.dim, 'batch': args.batch,
+                   'per_list_k': 2 * t, 'fused': t, 'ce_pairs_per_query': t, 'vocab': args.vocab,
+                   'embedder': args.embed_arch, 'cross_encoder': args.ce_arch,
+                   'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU'},
+        'stage_ms_per_step': stage_ms,
+        'roofline': roofline,
+    }
+    if args.cpu_queries > 0 and world == 1:
+        bi_cpu, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', 'cpu')
+        ce_cpu, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', 'cpu')
+        # GPU results for the sample, cross-encoder in fp32 like the host run
+        s32 = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
+                            chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=t,
+                            ce_dtype=torch.float32)
+        o = s32.search(queries[0]['ids'], queries[0]['mask'], queries[0]['qterms'], queries[0]['qoff'],
+                       queries[0]['n_terms'], queries[0]['ce_tok'], queries[0]['ce_off'])
+        torch.cuda.synchronize()
+        off_h = off.cpu().numpy()
+        tok_h = tok.cpu().numpy()
+        gpu_out = {'fused_row': o['fused_row'].cpu().numpy(), 'rows': o['rows'].cpu().numpy(),
+                   'chunk_tokens': lambda rs: [tok_h[off_h[r]:off_h[r + 1]].tolist() for r in rs]}
+        result['cpu_baseline'] = cpu_baseline(args, (bi_cpu, ce_cpu), rows, host, queries[0], gpu_out)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -383,6 +383,12 @@ struct rag_dense_s {
     int64_t row_base = 0;
     int device = 0;
     DevBuf scratch, cand, cand_count;
+    // optional timing of the scan kernel: a ring of event pairs on the launch stream
+    static constexpr int PROF_RING = 256;
+    bool profiling = false;
+    hipEvent_t ev0[PROF_RING], ev1[PROF_RING];
+    int prof_n = 0;
+    int last_strips = 0, last_qblocks = 0;
 };
 
 extern "C" int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t metric,
@@ -444,6 +450,7 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
     if (!h) return RAG_OK;
     if (h->owns_rows && h->rows) (void)hipFree(h->rows);
     if (h->row_norm2) (void)hipFree(h->row_norm2);
+    if (h->profiling) (void)rag_dense_profile(h, 0);
     h->scratch.release();
     h->cand.release();
     h->cand_count.release();
@@ -452,6 +459,39 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
 }
 
 extern "C" int64_t rag_dense_rows(rag_dense_t h) { return h ? h->n_rows : -1; }
+
+extern "C" int rag_dense_profile(rag_dense_t h, int32_t enable) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_profile: null handle");
+    if (enable && !h->profiling) {
+        for (int i = 0; i < rag_dense_s::PROF_RING; ++i) {
+            RAG_HIP_TRY(hipEventCreate(&h->ev0[i]));
+            RAG_HIP_TRY(hipEventCreate(&h->ev1[i]));
+        }
+        h->profiling = true;
+    }
+    if (!enable && h->profiling) {
+        for (int i = 0; i < rag_dense_s::PROF_RING; ++i) {
+            (void)hipEventDestroy(h->ev0[i]);
+            (void)hipEventDestroy(h->ev1[i]);
+        }
+        h->profiling = false;
+    }
+    h->prof_n = 0;
+    return RAG_OK;
+}
+
+extern "C" int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_n, int32_t* out_n) {
+    RAG_REQUIRE(h != nullptr && out_ms && out_n, RAG_EINVAL, "rag_dense_profile_read: null argument");
+    int n = h->profiling ? h->prof_n : 0;
+    if (n > max_n) n = max_n;
+    for (int i = 0; i < n; ++i) {
+        RAG_HIP_TRY(hipEventSynchronize(h->ev1[i]));
+        RAG_HIP_TRY(hipEventElapsedTime(&out_ms[i], h->ev0[i], h->ev1[i]));
+    }
+    *out_n = n;
+    h->prof_n = 0;
+    return RAG_OK;
+}
 
 namespace {
 
@@ -486,8 +526,16 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
                                         (int)Cfg::LDS_BYTES));
         attr_set[p.euclid] = true;
     }
+    const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING;
+    if (prof) RAG_HIP_TRY(hipEventRecord(h->ev0[h->prof_n], stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     RAG_HIP_TRY(hipGetLastError());
+    if (prof) {
+        RAG_HIP_TRY(hipEventRecord(h->ev1[h->prof_n], stream));
+        h->prof_n++;
+    }
+    h->last_strips = p.n_strips;
+    h->last_qblocks = p.n_qblocks;
     return RAG_OK;
 }
 

@@ -1,0 +1,198 @@
+"""Batched, device-resident form of the query path.
+
+The reference answers one query per call (``scripts/query.py:139-162``: hybrid search with
+``fetch_k = max(top_k, rerank_top_n)``, then rerank of the original query).  ``BatchSearcher``
+runs the same sequence for a whole batch of queries without leaving the GPU between stages:
+
+    embed (PyTorch)  ->  rag_dense_search_dev   \\
+                         rag_bm25_search_dev     -> rag_fuse_rrf_dev / rag_fuse_weighted_dev
+    -> rag_ce_pair_len_dev / rag_ce_pack_dev -> cross-encoder forward (PyTorch)
+    -> rag_topk_segmented_dev
+
+With ``dist`` set (one process per GPU, corpus rows sharded), each rank searches its own row
+range, the per-shard top-K lists are all-gathered (RCCL) and merged with ``rag_merge_topk_*``,
+fusion is replicated, the cross-encoder pairs are split across ranks by pair index and the
+logits all-gathered.  Global statistics (idf, avgdl, canon) are replicated so every score
+equals the unsharded one.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+import rag_hip
+
+
+@dataclass
+class StageTimes:
+    embed: float = 0.0
+    dense: float = 0.0
+    bm25: float = 0.0
+    fuse: float = 0.0
+    rerank: float = 0.0
+
+    def as_dict(self):
+        return dict(embed=self.embed, dense=self.dense, bm25=self.bm25, fuse=self.fuse, rerank=self.rerank)
+
+
+class TokenStore:
+    """CSR token ids of every chunk (global rows), resident on the GPU, for pair packing."""
+
+    def __init__(self, tok: torch.Tensor, off: torch.Tensor, row_base: int = 0):
+        assert tok.dtype == torch.int32 and off.dtype == torch.int64
+        self.tok, self.off, self.row_base = tok.contiguous(), off.contiguous(), int(row_base)
+
+
+class BatchSearcher:
+    def __init__(self, dense: Optional[rag_hip.DenseIndex], bm25: Optional[rag_hip.Bm25Index],
+                 canon: Optional[torch.Tensor] = None, bi_encoder=None, cross_encoder=None,
+                 chunk_tokens: Optional[TokenStore] = None, top_k: int = 5, rerank_top_n: int = 50,
+                 fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
+                 ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, ce_dtype=torch.bfloat16,
+                 special_ids=(101, 102, 0), dist=None):
+        self.dense, self.bm25, self.canon = dense, bm25, canon
+        self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
+        self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
+        self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
+        self.ce_pairs_per_batch, self.ce_max_len, self.ce_dtype = int(ce_pairs_per_batch), int(ce_max_len), ce_dtype
+        self.cls_id, self.sep_id, self.pad_id = special_ids
+        self.dist = dist                                  # torch.distributed module when sharded
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.times = StageTimes()
+        self.timing = False
+
+    # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
+    @property
+    def fetch_k(self):
+        return max(self.top_k, self.rerank_top_n if self.cross_encoder is not None else self.top_k)
+
+    def _timed(self, name, fn):
+        if not self.timing:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        b.synchronize()
+        setattr(self.times, name, getattr(self.times, name) + a.elapsed_time(b))
+        return out
+
+    # ---- stages ----------------------------------------------------------------------
+    @torch.no_grad()
+    def embed(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        return self.bi_encoder(ids, None, mask, normalize=True).contiguous()
+
+    def _gather_merge(self, score, row, cnt, k):
+        """all-gather the per-shard lists and merge them to the global top-k."""
+        if self.world == 1:
+            return score, row, cnt
+        b = score.shape[0]
+        gs = torch.empty((self.world,) + tuple(score.shape), dtype=score.dtype, device=score.device)
+        gr = torch.empty((self.world,) + tuple(row.shape), dtype=row.dtype, device=row.device)
+        gc = torch.empty((self.world, b), dtype=cnt.dtype, device=cnt.device)
+        self.dist.all_gather_into_tensor(gs, score)
+        self.dist.all_gather_into_tensor(gr, row)
+        self.dist.all_gather_into_tensor(gc, cnt)
+        return rag_hip.merge_topk_dev(gs.permute(1, 0, 2).contiguous(), gr.permute(1, 0, 2).contiguous(),
+                                      gc.t().contiguous(), k)
+
+    def dense_search(self, qvec: torch.Tensor, k: int):
+        s, r, c = self.dense.search_dev(qvec, k)
+        return self._gather_merge(s, r, c, k)
+
+    def bm25_search(self, qterms: torch.Tensor, qoff: torch.Tensor, n_terms: int, k: int):
+        s, r, c = self.bm25.search_dev(qterms, qoff, n_terms, k)
+        return self._gather_merge(s, r, c, k)
+
+    def fuse(self, vec, bm, t):
+        vs, vr, vc = vec
+        bs, br, bc = bm
+        if self.fusion_method == 'rrf':
+            return rag_hip.fuse_rrf_dev(vr, vc, br, bc, t, canon=self.canon)
+        return rag_hip.fuse_weighted_dev(vr, vs.double(), vc, br, bs, bc, t, self.vw, self.bw, canon=self.canon)
+
+    @torch.no_grad()
+    def rerank(self, q_tok: torch.Tensor, q_off: torch.Tensor, fused_row: torch.Tensor, fused_cnt: torch.Tensor):
+        """Cross-encoder scores of every (query, fused candidate) pair, then the per-query
+        stable top-k.  Returns (positions into the fused list [B, top_k], counts, logits [B, T])."""
+        b, t = fused_row.shape
+        dev = fused_row.device
+        n_pairs = b * t
+        pair_query = torch.arange(b, dtype=torch.int32, device=dev).repeat_interleave(t)
+        pair_row = fused_row.reshape(-1)
+        store = self.chunk_tokens
+        # this rank's share of the pairs (pure data parallel over pair index)
+        lo, hi = (n_pairs * self.rank) // self.world, (n_pairs * (self.rank + 1)) // self.world
+        my_q, my_r = pair_query[lo:hi].contiguous(), pair_row[lo:hi].contiguous()
+        n_mine = hi - lo
+        logits_mine = torch.zeros((n_mine,), dtype=torch.float32, device=dev)
+        if n_mine:
+            plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
+            order = torch.argsort(plen, descending=True)
+            sorted_len = plen[order]
+            # longest pair of every mini-batch (one small copy to the host sizes the buffers)
+            starts = list(range(0, n_mine, self.ce_pairs_per_batch))
+            heads = sorted_len[torch.tensor(starts, device=dev)].cpu().tolist()
+            for s0, longest in zip(starts, heads):
+                s1 = min(s0 + self.ce_pairs_per_batch, n_mine)
+                if longest <= 0:
+                    continue                               # only empty slots (row -1) left
+                seq = max(8, (int(longest) + 7) // 8 * 8)
+                idx = order[s0:s1]
+                ids, types, mask = rag_hip.ce_pack_dev(
+                    q_tok, q_off, store.tok, store.off, store.row_base, my_q[idx].contiguous(),
+                    my_r[idx].contiguous(), None, s1 - s0, seq, self.cls_id, self.sep_id, self.pad_id)
+                with torch.autocast('cuda', dtype=self.ce_dtype, enabled=self.ce_dtype != torch.float32):
+                    out = self.cross_encoder(ids, types, mask)
+                logits_mine[idx] = out.float()
+        if self.world > 1:
+            sizes = [(n_pairs * (r + 1)) // self.world - (n_pairs * r) // self.world for r in range(self.world)]
+            parts = [torch.empty((s,), dtype=torch.float32, device=dev) for s in sizes]
+            self.dist.all_gather(parts, logits_mine)
+            logits = torch.cat(parts)
+        else:
+            logits = logits_mine
+        # pools are the first fused_cnt[q] entries of each row: pack them back to back
+        seg_off = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
+        seg_off[1:] = torch.cumsum(fused_cnt, 0)
+        logits = logits.reshape(b, t)
+        if bool((fused_cnt == t).all()):
+            flat = logits.reshape(-1).contiguous()
+        else:
+            keep = torch.arange(t, device=dev)[None, :] < fused_cnt[:, None]
+            flat = logits[keep].contiguous()
+        idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
+        return idx, cnt, logits
+
+    # ---- whole path ------------------------------------------------------------------
+    def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):
+        """One batch through the whole path.  Returns dict of device tensors:
+        rows [B, top_k] (global), fused_score f64 [B, top_k], rerank_score f32 (if reranked)."""
+        t = self.fetch_k
+        k_list = min(2 * t, rag_hip.MAX_K)
+        vec = bm = None
+        if self.dense is not None:
+            qvec = self._timed('embed', lambda: self.embed(embed_ids, embed_mask))
+            vec = self._timed('dense', lambda: self.dense_search(qvec, k_list))
+        if self.bm25 is not None:
+            bm = self._timed('bm25', lambda: self.bm25_search(qterms, qoff, n_terms, k_list))
+        b = (vec or bm)[1].shape[0]
+        dev = (vec or bm)[1].device
+        if vec is None:
+            vec = (torch.zeros((b, 1), dtype=torch.float32, device=dev), torch.full((b, 1), -1, dtype=torch.int64, device=dev),
+                   torch.zeros((b,), dtype=torch.int32, device=dev))
+        if bm is None:
+            bm = (torch.zeros((b, 1), dtype=torch.float64, device=dev), torch.full((b, 1), -1, dtype=torch.int64, device=dev),
+                  torch.zeros((b,), dtype=torch.int32, device=dev))
+        pos, row, score, cnt = self._timed('fuse', lambda: self.fuse(vec, bm, t))
+        out = {'fused_row': row, 'fused_score': score, 'fused_count': cnt}
+        if self.cross_encoder is None:
+            out.update(rows=row[:, :self.top_k], scores=score[:, :self.top_k], count=torch.clamp(cnt, max=self.top_k))
+            return out
+        idx, rc, logits = self._timed('rerank', lambda: self.rerank(ce_q_tok, ce_q_off, row, cnt))
+        safe = idx.clamp(min=0).long()
+        out.update(rows=torch.where(idx >= 0, torch.gather(row, 1, safe), torch.full_like(safe, -1)),
+                   scores=torch.gather(score, 1, safe), rerank_score=torch.gather(logits, 1, safe), count=rc,
+                   rerank_pos=idx)
+        return out

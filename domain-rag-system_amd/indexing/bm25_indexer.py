@@ -52,8 +52,12 @@ class Bm25Arrays:
         return tf * (k1 + 1) / (tf + norm[self.rows])
 
 
-def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b):
-    """Flat token occurrences (term id, doc id) -> CSR + statistics."""
+def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=None):
+    """Flat token occurrences (term id, doc id) -> CSR + statistics.
+
+    ``global_stats`` (row-sharded corpora): ``{'df': int64[V], 'total_len': int, 'n_docs': int}``
+    summed over all shards; idf and avgdl then come from the whole corpus, so every document
+    scores exactly as it would in an unsharded index, while the postings stay local."""
     n_docs = int(doc_len.shape[0])
     v = len(vocab) if not isinstance(vocab, int) else vocab
     if n_docs == 0:
@@ -65,6 +69,12 @@ def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b):
     df = np.bincount(post_term, minlength=v).astype(np.int64)
     indptr = np.zeros(v + 1, np.int64)
     np.cumsum(df, out=indptr[1:])
+    n_local = n_docs
+    total_len = int(doc_len.sum())
+    if global_stats is not None:
+        df = np.asarray(global_stats['df'], np.int64)
+        n_docs = int(global_stats['n_docs'])
+        total_len = int(global_stats['total_len'])
     # idf with libm's log, summed in vocabulary (first appearance) order
     idf = np.zeros(v, np.float64)
     total = 0
@@ -79,7 +89,8 @@ def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b):
     if present:
         floor = _EPSILON * (total / present)
         idf[(idf < 0) & (df > 0)] = floor
-    avgdl = int(doc_len.sum()) / n_docs
+    avgdl = total_len / n_docs
+    assert doc_len.shape[0] == n_local
     return Bm25Arrays(vocab, indptr, rows, tf.astype(np.uint32), idf, doc_len.astype(np.int64), avgdl, k1, b)
 
 

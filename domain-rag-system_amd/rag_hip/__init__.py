@@ -34,6 +34,8 @@ SIGNATURES = {
     'rag_dense_create': (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
     'rag_dense_destroy': (_i32, [_vp]),
     'rag_dense_rows': (_i64, [_vp]),
+    'rag_dense_profile': (_i32, [_vp, _i32]),
+    'rag_dense_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_dense_search_dev': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'rag_dense_search': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     'rag_dense_rescore_dev': (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
@@ -73,6 +75,13 @@ def load_library():
                 raise RagHipError(
                     f"{LIB_PATH} is missing: build it with `make -C domain-rag-system_amd/csrc` "
                     "(or __graft_entry__.build()); this package has no CPU fallback")
+            # PyTorch ships its own copy of the HIP runtime (same SONAME as /opt/rocm's).  Two
+            # copies in one process fight over the device, so when torch is installed its copy
+            # must be the one already loaded when this library resolves libamdhip64.so.7.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
@@ -204,6 +213,16 @@ class DenseIndex:
         check(lib().rag_dense_search_dev(self._h, _ptr(queries), b, int(k), _ptr(row_mask), _ptr(score), _ptr(row),
                                          _ptr(cnt), _stream()), 'rag_dense_search_dev')
         return score, row, cnt
+
+    def profile(self, enable=True):
+        check(lib().rag_dense_profile(self._h, 1 if enable else 0), 'rag_dense_profile')
+
+    def profile_read(self):
+        """Durations (ms) of the scan kernels launched since the last read."""
+        buf = np.zeros(256, np.float32)
+        n = _i32(0)
+        check(lib().rag_dense_profile_read(self._h, buf.ctypes.data, 256, C.byref(n)), 'rag_dense_profile_read')
+        return buf[:n.value].copy()
 
     def rescore(self, queries, cand_rows):
         q, _ = _np(queries, np.float32)

@@ -72,6 +72,11 @@ int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t met
                      int32_t mem_kind, int64_t row_base, rag_dense_t* out);
 int rag_dense_destroy(rag_dense_t h);
 int64_t rag_dense_rows(rag_dense_t h);
+/* Measurement aid (no counterpart in the reference): while enabled, every search records a
+ * HIP event pair around its scan kernel on the launch stream (up to 256 searches);
+ * rag_dense_profile_read waits for them and returns the kernel durations in ms.      */
+int rag_dense_profile(rag_dense_t h, int32_t enable);
+int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_n, int32_t* out_n);
 
 /* queries [n_queries x dim] fp32 (already normalised for cosine).  row_mask: NULL or
  * one byte per LOCAL row, 0 = excluded (the payload filter of

@@ -18,7 +18,9 @@ def _text_corpus(n, seed):
     for _ in range(n):
         ln = int(rng.integers(0, 30))
         docs.append([WORDS[int(i)] for i in rng.integers(0, len(WORDS), ln)])
-    docs[0] = ['the'] * 5            # a term in more than half the documents gets the epsilon floor
+    for i in range(n):                # 'common' sits in 4 of 5 documents: negative raw idf
+        if i % 5:
+            docs[i].append('common')
     return docs
 
 
@@ -41,7 +43,7 @@ def test_bm25_scores_bit_identical_to_literal_form(n, seed):
     for w, t in a.vocab.items():
         assert a.idf[t] == lit.idf[w], w
     queries = [['aspirin', 'pain'], ['the', 'the', 'of'], ['zzz_oov'], [], ['liver', 'zzz', 'liver', 'kidney', 'the'],
-               ['dose'] * 7]
+               ['dose'] * 7, ['common', 'heart']]
     for q in queries:
         got = ix._device_index.scores(ix.term_ids(q))
         want = lit.get_scores(q)
@@ -51,8 +53,10 @@ def test_bm25_scores_bit_identical_to_literal_form(n, seed):
 def test_bm25_negative_idf_floor_is_exercised():
     docs = _text_corpus(300, 5)
     lit = BM25OkapiLiteral(docs)
-    assert any(v < 0 for v in [lit.idf[w] for w in lit.idf]) or lit.average_idf < 0 or \
-        any(abs(lit.idf[w] - 0.25 * lit.average_idf) < 1e-15 for w in lit.idf)
+    assert lit.idf['common'] == 0.25 * lit.average_idf          # the epsilon floor replaced a negative idf
+    ix = _build_product(docs)
+    q = ['common', 'aspirin', 'common']
+    assert np.array_equal(ix._device_index.scores(ix.term_ids(q)), lit.get_scores(q))
 
 
 @pytest.mark.parametrize('n_docs,vocab,b,k', [(3000, 500, 40, 10), (20000, 5000, 64, 20), (9000, 2000, 30, 200),
