@@ -221,11 +221,11 @@ def main():
 
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
     bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev)
-    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev)
     ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
+    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
-                             rerank_top_n=args.rerank_top_n, ce_dtype=ce_dtype, dist=dist)
+                             rerank_top_n=args.rerank_top_n, dist=dist)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
 
@@ -299,9 +299,9 @@ def main():
         bi_cpu, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', 'cpu')
         ce_cpu, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', 'cpu')
         # GPU results for the sample, cross-encoder in fp32 like the host run
-        s32 = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
-                            chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=t,
-                            ce_dtype=torch.float32)
+        ce32, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32)
+        s32 = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce32,
+                            chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=t)
         o = s32.search(queries[0]['ids'], queries[0]['mask'], queries[0]['qterms'], queries[0]['qoff'],
                        queries[0]['n_terms'], queries[0]['ce_tok'], queries[0]['ce_off'])
         torch.cuda.synchronize()

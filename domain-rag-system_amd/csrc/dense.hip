@@ -19,6 +19,7 @@
 #include "merge.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -567,6 +568,10 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     p.k = k;
     int cap = 2 * k + BN;
     if (cap < 3 * BN) cap = 3 * BN;
+    if (const char* e = getenv("RAG_DENSE_CAP")) {      // tuning aid: candidate list capacity
+        int v = atoi(e);
+        if (v >= k + BN && v <= 8192) cap = v;
+    }
     p.cap = (cap + 63) / 64 * 64;
     p.euclid = h->metric == RAG_METRIC_EUCLID;
     int rc;

@@ -48,13 +48,12 @@ class BatchSearcher:
                  canon: Optional[torch.Tensor] = None, bi_encoder=None, cross_encoder=None,
                  chunk_tokens: Optional[TokenStore] = None, top_k: int = 5, rerank_top_n: int = 50,
                  fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
-                 ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, ce_dtype=torch.bfloat16,
-                 special_ids=(101, 102, 0), dist=None):
+                 ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
         self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
-        self.ce_pairs_per_batch, self.ce_max_len, self.ce_dtype = int(ce_pairs_per_batch), int(ce_max_len), ce_dtype
+        self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
         self.cls_id, self.sep_id, self.pad_id = special_ids
         self.dist = dist                                  # torch.distributed module when sharded
         self.world = dist.get_world_size() if dist is not None else 1
@@ -88,14 +87,17 @@ class BatchSearcher:
         if self.world == 1:
             return score, row, cnt
         b = score.shape[0]
-        gs = torch.empty((self.world,) + tuple(score.shape), dtype=score.dtype, device=score.device)
-        gr = torch.empty((self.world,) + tuple(row.shape), dtype=row.dtype, device=row.device)
-        gc = torch.empty((self.world, b), dtype=cnt.dtype, device=cnt.device)
-        self.dist.all_gather_into_tensor(gs, score)
-        self.dist.all_gather_into_tensor(gr, row)
-        self.dist.all_gather_into_tensor(gc, cnt)
-        return rag_hip.merge_topk_dev(gs.permute(1, 0, 2).contiguous(), gr.permute(1, 0, 2).contiguous(),
-                                      gc.t().contiguous(), k)
+        kk = score.shape[1]
+        # outputs are the ranks' tensors concatenated along dim 0: [world * B, k]
+        gs = torch.empty((self.world * b, kk), dtype=score.dtype, device=score.device)
+        gr = torch.empty((self.world * b, kk), dtype=row.dtype, device=row.device)
+        gc = torch.empty((self.world * b,), dtype=cnt.dtype, device=cnt.device)
+        self.dist.all_gather_into_tensor(gs, score.contiguous())
+        self.dist.all_gather_into_tensor(gr, row.contiguous())
+        self.dist.all_gather_into_tensor(gc, cnt.contiguous())
+        return rag_hip.merge_topk_dev(gs.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
+                                      gr.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
+                                      gc.view(self.world, b).t().contiguous(), k)
 
     def dense_search(self, qvec: torch.Tensor, k: int):
         s, r, c = self.dense.search_dev(qvec, k)
@@ -122,11 +124,13 @@ class BatchSearcher:
         pair_query = torch.arange(b, dtype=torch.int32, device=dev).repeat_interleave(t)
         pair_row = fused_row.reshape(-1)
         store = self.chunk_tokens
-        # this rank's share of the pairs (pure data parallel over pair index)
-        lo, hi = (n_pairs * self.rank) // self.world, (n_pairs * (self.rank + 1)) // self.world
+        # this rank's share of the pairs (pure data parallel over pair index; equal shares,
+        # the last one padded, so one fixed-size all-gather returns every logit)
+        share = (n_pairs + self.world - 1) // self.world
+        lo, hi = min(n_pairs, share * self.rank), min(n_pairs, share * (self.rank + 1))
         my_q, my_r = pair_query[lo:hi].contiguous(), pair_row[lo:hi].contiguous()
         n_mine = hi - lo
-        logits_mine = torch.zeros((n_mine,), dtype=torch.float32, device=dev)
+        logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
             order = torch.argsort(plen, descending=True)
@@ -143,14 +147,12 @@ class BatchSearcher:
                 ids, types, mask = rag_hip.ce_pack_dev(
                     q_tok, q_off, store.tok, store.off, store.row_base, my_q[idx].contiguous(),
                     my_r[idx].contiguous(), None, s1 - s0, seq, self.cls_id, self.sep_id, self.pad_id)
-                with torch.autocast('cuda', dtype=self.ce_dtype, enabled=self.ce_dtype != torch.float32):
-                    out = self.cross_encoder(ids, types, mask)
+                out = self.cross_encoder(ids, types, mask)
                 logits_mine[idx] = out.float()
         if self.world > 1:
-            sizes = [(n_pairs * (r + 1)) // self.world - (n_pairs * r) // self.world for r in range(self.world)]
-            parts = [torch.empty((s,), dtype=torch.float32, device=dev) for s in sizes]
-            self.dist.all_gather(parts, logits_mine)
-            logits = torch.cat(parts)
+            gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
+            self.dist.all_gather_into_tensor(gathered, logits_mine)
+            logits = gathered[:n_pairs]
         else:
             logits = logits_mine
         # pools are the first fused_cnt[q] entries of each row: pack them back to back

@@ -432,6 +432,21 @@ def merge_topk_dev(score, row, count, k_out, smaller_is_better=False):
     return out_s, out_r, out_c
 
 
+def topk_stable_f64(scores, top_k):
+    """Positions of the best ``top_k`` fp64 scores, best first, equal scores in input order
+    (rag_merge_topk_f64_dev; its tie rule prefers the larger row, so position i travels as
+    row n-1-i)."""
+    import torch
+    n = len(scores)
+    if n == 0:
+        return []
+    dev = torch.device('cuda')
+    s64 = torch.tensor(list(scores), dtype=torch.float64, device=dev).reshape(1, 1, n)
+    rows = torch.arange(n - 1, -1, -1, dtype=torch.int64, device=dev).reshape(1, 1, n)
+    _, r, c = merge_topk_dev(s64, rows, None, min(int(top_k), MAX_K))
+    return [n - 1 - int(x) for x in r[0, :int(c[0])].cpu()]
+
+
 def ce_pair_len_dev(query_off, chunk_off, chunk_row_base, pair_query, pair_row, max_len):
     import torch
     n = pair_row.shape[0]

@@ -58,13 +58,8 @@ class BaseReranker:
         if np.array_equal(s32.astype(np.float64), np.asarray(scores, dtype=np.float64)):
             idx, cnt = rag_hip.topk_segmented(s32, [0, n], k)
             return [int(i) for i in idx[0, :int(cnt[0])]]
-        # scores that are not float32 values: fp64 merge kernel; its tie rule prefers the
-        # larger row, so position i travels as row n-1-i
-        dev = torch.device('cuda')
-        s64 = torch.tensor(scores, dtype=torch.float64, device=dev).reshape(1, 1, n)
-        rows = torch.arange(n - 1, -1, -1, dtype=torch.int64, device=dev).reshape(1, 1, n)
-        _, r, c = rag_hip.merge_topk_dev(s64, rows, None, k)
-        return [n - 1 - int(x) for x in r[0, :int(c[0])].cpu()]
+        # scores that are not float32 values are ordered on their fp64 values
+        return rag_hip.topk_stable_f64(scores, k)
 
 
 class SimpleSimilarityReranker(BaseReranker):

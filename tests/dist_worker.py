@@ -1,0 +1,83 @@
+"""Worker for the world_size-2 gloo test (TEST INFRASTRUCTURE): one rank of the row-sharded
+batched query path, GPU entry points replaced by the oracle-backed doubles."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'domain-rag-system_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def make_world(n=600, dim=64, vocab=300, seed=0):
+    from tests import synth
+    corpus = synth.dense_corpus(n, dim, seed=seed)
+    term, doc, ln = synth.sparse_corpus(n, vocab, seed=seed + 1, mean_len=12)
+    term, _, v = synth.remap_first_appearance(term, vocab)
+    rng = np.random.default_rng(seed + 2)
+    canon = np.arange(n, dtype=np.uint32)
+    for d in (40, 300, 301, 555):
+        canon[d] = canon[int(rng.integers(0, d))]
+    clen = ln + 2
+    off = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+    tok = rng.integers(1000, 4096, size=int(off[-1])).astype(np.int32)
+    b = 9
+    q_ids = np.zeros((b, 8), np.int64)
+    q_ids[:, 0], q_ids[:, 7] = 101, 102
+    q_ids[:, 1:7] = rng.integers(1000, 4096, size=(b, 6))
+    bm_q = synth.sparse_queries(term, doc, ln, v, b, seed=seed + 3)
+    return dict(corpus=corpus, term=term, doc=doc, ln=ln, v=v, canon=canon, tok=tok, off=off, q_ids=q_ids, bm_q=bm_q)
+
+
+def run_rank(rank, world, port, out_path, fusion='rrf'):
+    import types
+    from tests import fake_backend
+    import rag_hip
+    for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
+                 'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev',
+                 'ce_pack_dev'):
+        setattr(rag_hip, name, getattr(fake_backend, name))
+    from indexing import bert
+    from indexing.batch import BatchSearcher, TokenStore
+    from indexing.bm25_indexer import build_arrays
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    w = make_world()
+    n = w['corpus'].shape[0]
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    sel = (w['doc'] >= lo) & (w['doc'] < hi)
+    stats = None
+    if world > 1:
+        df = np.bincount(np.unique(w['term'] * n + w['doc']) // n, minlength=w['v'])
+        stats = dict(df=df, total_len=int(w['ln'].sum()), n_docs=n)
+    arr = build_arrays(w['term'][sel], w['doc'][sel] - lo, w['ln'][lo:hi], w['v'], 1.5, 0.75, global_stats=stats)
+    dense = rag_hip.DenseIndex(w['corpus'][lo:hi], row_base=lo)
+    bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, hi - lo, row_base=lo)
+    bi, _, _ = bert.load_model('random:tiny', 'bi', 'cpu')
+    ce, _, _ = bert.load_model('random:tiny', 'cross', 'cpu')
+    s = BatchSearcher(dense, bm25, canon=torch.from_numpy(w['canon']), bi_encoder=bi, cross_encoder=ce,
+                      chunk_tokens=TokenStore(torch.from_numpy(w['tok']), torch.from_numpy(w['off'])),
+                      top_k=4, rerank_top_n=11, fusion_method=fusion, vector_weight=0.6, bm25_weight=0.4,
+                      ce_pairs_per_batch=16, dist=dist)
+    qterms, qoff = rag_hip.Bm25Index.flatten(w['bm_q'])
+    ids = torch.from_numpy(w['q_ids'])
+    ce_tok = torch.from_numpy(w['q_ids'][:, 1:7].astype(np.int32).reshape(-1).copy())
+    ce_off = torch.arange(ids.shape[0] + 1, dtype=torch.int64) * 6
+    out = s.search(ids, torch.ones_like(ids), torch.from_numpy(qterms), torch.from_numpy(qoff), int(qoff[-1]),
+                   ce_tok, ce_off)
+    if rank == 0:
+        torch.save({k: v for k, v in out.items()}, out_path)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    run_rank(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])

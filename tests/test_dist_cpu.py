@@ -1,0 +1,40 @@
+"""CPU: the row-sharded query path over gloo with world_size 2 gives the unsharded answer.
+Kernels are replaced by oracle-backed doubles; what is under test is the exchange: global
+BM25 statistics, per-shard lists with global row ids, all-gather + merge, replicated fusion,
+cross-encoder pairs split across ranks, logits all-gather."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out_path, fusion):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
+                               out_path, fusion]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    return torch.load(out_path, weights_only=True)
+
+
+@pytest.mark.parametrize('fusion', ['rrf', 'weighted'])
+def test_two_shards_equal_one(tmp_path, fusion):
+    one = _run(1, str(tmp_path / 'one.pt'), fusion)
+    two = _run(2, str(tmp_path / 'two.pt'), fusion)
+    assert torch.equal(one['fused_row'], two['fused_row'])
+    assert torch.equal(one['fused_score'], two['fused_score'])          # fp64, bit for bit
+    assert torch.equal(one['fused_count'], two['fused_count'])
+    assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
+    assert torch.allclose(one['rerank_score'], two['rerank_score'], atol=1e-5)
+    assert one['rows'].shape == (9, 4) and int(one['count'].min()) == 4

@@ -1,0 +1,88 @@
+"""GPU: BASELINE.json's full sizes (1M x 768, 1M documents), checked through properties that
+do not need the oracle to finish a brute-force pass per query: sortedness, exact re-scoring of
+the returned rows, self-retrieval, a threshold property against sampled rows, agreement of the
+BM25 top-k with a host sort of the kernel's own dense score vector, and bit-equality of that
+score vector with the oracle for a few queries."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+N, DIM, VOCAB = 1_000_000, 768, 200_000
+
+
+@pytest.fixture(scope='module')
+def dense():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(5)
+    rows = torch.nn.functional.normalize(torch.randn((N, DIM), generator=g, device=dev), dim=1)
+    return rows, rag_hip.DenseIndex(rows, borrow=True)
+
+
+@pytest.mark.parametrize('b,k', [(1024, 100), (37, 10), (1, 10)])
+def test_dense_1m_properties(dense, b, k):
+    rows, idx = dense
+    dev = rows.device
+    g = torch.Generator(device=dev).manual_seed(b)
+    q = torch.nn.functional.normalize(torch.randn((b, DIM), generator=g, device=dev), dim=1)
+    pick = torch.randint(0, N, (b // 2 + 1,), generator=g, device=dev)
+    q[: pick.shape[0]] = torch.nn.functional.normalize(rows[pick] + 0.02 * q[: pick.shape[0]], dim=1)
+    score, row, cnt = idx.search_dev(q, k)
+    torch.cuda.synchronize()
+    assert bool((cnt == k).all())
+    # best first; equal scores by row descending
+    s, r = score, row
+    assert bool(((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (r[:, :-1] > r[:, 1:]))).all())
+    assert bool((r >= 0).all()) and bool((r < N).all())
+    # the near-duplicate query finds its source row first
+    assert bool((row[: pick.shape[0], 0] == pick).all())
+    # every returned score is the row's exact dot product (independent kernel + torch fp64)
+    again = idx.rescore_dev(q, row)
+    exact = torch.einsum('bkd,bd->bk', rows[row].double(), q.double())
+    torch.cuda.synchronize()
+    assert float((score - again).abs().max()) < 1e-5
+    assert float((score.double() - exact).abs().max()) < 1e-5
+    # nothing outside the list beats the k-th score: 4096 sampled rows per query + full check for 4 queries
+    samp = torch.randint(0, N, (4096,), generator=g, device=dev)
+    sims = q @ rows[samp].t()
+    in_list = (samp[None, :, None] == row[:, None, :]).any(dim=2)
+    assert bool(((sims <= score[:, -1:] + 1e-6) | in_list).all())
+    for i in range(min(b, 4)):
+        full = rows @ q[i]
+        top = torch.topk(full, k)
+        assert set(top.indices.tolist()) == set(row[i].tolist()) or \
+            float((top.values - score[i]).abs().max()) < 2e-6
+
+
+def test_bm25_1m_properties():
+    import rag_hip
+    from indexing.bm25_indexer import build_arrays
+    from oracle.bm25_ref import BM25OkapiArrays
+    dev = torch.device('cuda:0')
+    term, doc, ln = synth.sparse_corpus(N, VOCAB, seed=2000)
+    arr = build_arrays(term, doc, ln, VOCAB, 1.5, 0.75)
+    idx = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, N)
+    rng = np.random.default_rng(3)
+    cdf = np.cumsum(synth.zipf_probs(VOCAB))
+    queries = []
+    for i in range(64):
+        n = int(rng.integers(3, 13))
+        queries.append(np.minimum(np.searchsorted(cdf, rng.random(n)), VOCAB - 1).astype(np.int32).tolist())
+    queries[5] = [-1, -1, -1]                       # out of vocabulary: every score zero
+    queries[6] = queries[7][:2] + queries[7][:2]    # repeated tokens count again
+    k = 200
+    score, row, cnt = idx.search(queries, k)
+    assert np.all(cnt == k)
+    for i in (0, 5, 6, 11, 40, 63):
+        dense_scores = idx.scores(queries[i])
+        order = np.argsort(dense_scores, kind='stable')[::-1][:k]
+        assert np.array_equal(row[i], order)
+        assert np.array_equal(score[i], dense_scores[order])
+    assert list(row[5]) == list(range(N - 1, N - 1 - k, -1)) and np.all(score[5] == 0)
+    ref = BM25OkapiArrays.from_token_ids(term, doc, ln, VOCAB)
+    assert np.array_equal(ref.idf, arr.idf)
+    for i in (0, 6, 40):
+        assert np.array_equal(idx.scores(queries[i]), ref.get_scores_ids(queries[i]))
