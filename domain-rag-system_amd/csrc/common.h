@@ -105,17 +105,20 @@ __device__ __forceinline__ bool sel_pass(const SelThr<KeyT>& t, KeyT key, uint32
     return a > t.pk || (a == t.pk && (row & t.mr) >= t.pr);
 }
 
-// LDS scratch needed by one radix_select group: 256 histogram bins + 4 broadcast words.
-#define RAG_SEL_LDS_WORDS 260
+// LDS scratch needed by one radix_select group: 256 histogram bins + 8 broadcast words.
+#define RAG_SEL_LDS_WORDS 264
 
 // NT = threads in the cooperating group: 64 (one wave, other waves of the block may be
 // doing something else) or the whole block (then every thread of the block must call).
 // get(i, key, row) loads item i; n = number of items; requires 1 <= K <= n.
+//
+// Keys of one list usually share their high bits (scores of one query lie in a narrow
+// range), so the key passes start at the highest bit in which any two keys differ: the first
+// histogram then spreads the items over its 256 bins instead of piling them onto one.
 template <typename KeyT, int NT, typename Get>
 __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds, int tid) {
-    constexpr int KEY_BYTES = (int)sizeof(KeyT);
     uint32_t* hist = lds;
-    uint32_t* bc = lds + 256;
+    uint32_t* bc = lds + 256;          // [0..2] digit/above/inbin, [4..5] OR of key differences
     SelThr<KeyT> t;
     t.pk = 0; t.mk = 0; t.pr = 0; t.mr = 0;
     uint32_t krem = (uint32_t)K;
@@ -129,28 +132,8 @@ __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds
             __syncthreads();
         }
     };
-
-    for (int pass = 0; pass < KEY_BYTES + 4; ++pass) {
-        for (int b = tid; b < 256; b += NT) hist[b] = 0;
-        gsync();
-        const bool on_key = pass < KEY_BYTES;
-        const int shift = on_key ? 8 * (KEY_BYTES - 1 - pass) : 8 * (3 - (pass - KEY_BYTES));
-        for (int i = tid; i < n; i += NT) {
-            KeyT key; uint32_t row;
-            get(i, key, row);
-            bool match;
-            uint32_t digit;
-            if (on_key) {
-                match = (key & t.mk) == t.pk;
-                digit = (uint32_t)(key >> shift) & 255u;
-            } else {
-                match = (key == t.pk) && ((row & t.mr) == t.pr);
-                digit = (row >> shift) & 255u;
-            }
-            if (match) atomicAdd(&hist[digit], 1u);
-        }
-        gsync();
-        // one wave finds the digit d with  #(digit > d) < krem <= #(digit >= d)
+    // one wave finds the digit d with  #(digit > d) < krem <= #(digit >= d)
+    auto pick_digit = [&]() {
         if (tid < 64) {
             const int l = tid;
             uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
@@ -173,17 +156,76 @@ __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds
                 c += hh[j];
             }
         }
-        gsync();
-        const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
-        if (on_key) {
-            t.pk |= (KeyT)d << shift;
-            t.mk |= (KeyT)255u << shift;
-        } else {
-            t.pr |= d << shift;
-            t.mr |= 255u << shift;
+    };
+
+    // ---- which key bits differ at all?
+    if (tid == 0) { bc[4] = 0; bc[5] = 0; }
+    gsync();
+    {
+        KeyT key0; uint32_t row0;
+        get(0, key0, row0);
+        KeyT diff = 0;
+        for (int i = tid; i < n; i += NT) {
+            KeyT key; uint32_t row;
+            get(i, key, row);
+            diff |= key ^ key0;
         }
-        krem -= above;
-        if (inbin == krem) break;               // every item of this bin is wanted
+        if (diff) {
+            atomicOr(&bc[4], (uint32_t)diff);
+            if constexpr (sizeof(KeyT) == 8) atomicOr(&bc[5], (uint32_t)((uint64_t)diff >> 32));
+        }
+        gsync();
+        KeyT all = (KeyT)bc[4];
+        if constexpr (sizeof(KeyT) == 8) all |= (KeyT)((uint64_t)bc[5] << 32);
+        // smear the highest differing bit downwards: low = every bit position at or below it
+        KeyT low = all;
+        low |= low >> 1; low |= low >> 2; low |= low >> 4; low |= low >> 8; low |= low >> 16;
+        if constexpr (sizeof(KeyT) == 8) low |= low >> 32;
+        t.mk = ~low;                                        // the keys agree on these bits
+        t.pk = key0 & t.mk;
+        const int n_low = sizeof(KeyT) == 8 ? __popcll((unsigned long long)low) : __popc((unsigned int)low);
+        bool done = false;
+        // ---- key passes, 8 bits at a time from bit `hi` down
+        int shift = n_low;
+        while (shift > 0 && !done) {
+            const int lo = shift > 8 ? shift - 8 : 0;
+            const uint32_t wmask = (1u << (shift - lo)) - 1u;
+            for (int b = tid; b < 256; b += NT) hist[b] = 0;
+            gsync();
+            for (int i = tid; i < n; i += NT) {
+                KeyT key; uint32_t row;
+                get(i, key, row);
+                if ((key & t.mk) == t.pk) atomicAdd(&hist[(uint32_t)(key >> lo) & wmask], 1u);
+            }
+            gsync();
+            pick_digit();
+            gsync();
+            const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
+            t.pk |= (KeyT)d << lo;
+            t.mk |= (KeyT)wmask << lo;
+            krem -= above;
+            done = inbin == krem;                       // every item of this bin is wanted
+            shift = lo;
+        }
+        // ---- equal keys: order by row, one byte at a time
+        for (int pass = 0; pass < 4 && !done; ++pass) {
+            const int lo = 8 * (3 - pass);
+            for (int b = tid; b < 256; b += NT) hist[b] = 0;
+            gsync();
+            for (int i = tid; i < n; i += NT) {
+                KeyT key; uint32_t row;
+                get(i, key, row);
+                if (key == t.pk && (row & t.mr) == t.pr) atomicAdd(&hist[(row >> lo) & 255u], 1u);
+            }
+            gsync();
+            pick_digit();
+            gsync();
+            const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
+            t.pr |= d << lo;
+            t.mr |= 255u << lo;
+            krem -= above;
+            done = inbin == krem;
+        }
     }
     gsync();
     return t;

@@ -45,7 +45,9 @@ struct DenseScanParams {
     uint2* scratch;             // [n_blocks][BQ][cap]  (key, local row)
     uint2* cand;                // [n_queries][n_strips][k]
     int32_t* cand_count;        // [n_queries][n_strips]
+    uint32_t* tau_shared;       // [n_queries] key of a lower bound of each query's final K-th score
     int euclid;
+    int debug_row_mod;          // tuning aid: when > 0, row loads wrap at this many rows (results meaningless)
 };
 
 template <int WQ, int TQ, int WR, int TR>
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
             int64_t grow = trow0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (grow < row_end && kb + k4 < p.dim)
-                v = *reinterpret_cast<const float4*>(p.rows + grow * p.dim + kb + k4);
+                v = *reinterpret_cast<const float4*>(p.rows + (p.debug_row_mod > 0 ? grow % p.debug_row_mod : grow) * p.dim + kb + k4);
             e_reg[i] = v;
         }
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
                     }
                     float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
                     m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
-                    const bool any = qvalid && m >= tauq;
+                    const bool any = qvalid && m >= tauq && p.debug_row_mod >= 0;
                     if (__ballot(any)) {             // rare once the threshold has warmed up
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -284,7 +286,15 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
                     if (lane == 0) {
                         cnt_s[q] = p.k;
                         tau_s[q] = key_to_f32(kmin);
+                        // K rows of this strip reach kmin, so the final K-th score does too
+                        if (q0 + q < p.n_queries) atomicMax(&p.tau_shared[q0 + q], kmin);
                     }
+                }
+                // adopt the best lower bound any strip has published for this query
+                if (!last_tile && ql < (wave + 1) * (BQ / NW) && q0 + ql < p.n_queries) {
+                    uint32_t g = __hip_atomic_load(&p.tau_shared[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    float tg = key_to_f32(g);
+                    if (tg > tau_s[ql]) tau_s[ql] = tg;
                 }
             }
             __syncthreads();
@@ -383,7 +393,7 @@ struct rag_dense_s {
     int metric = 0;
     int64_t row_base = 0;
     int device = 0;
-    DevBuf scratch, cand, cand_count;
+    DevBuf scratch, cand, cand_count, tau_shared;
     // optional timing of the scan kernel: a ring of event pairs on the launch stream
     static constexpr int PROF_RING = 256;
     bool profiling = false;
@@ -455,6 +465,7 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
     h->scratch.release();
     h->cand.release();
     h->cand_count.release();
+    h->tau_shared.release();
     delete h;
     return RAG_OK;
 }
@@ -500,8 +511,10 @@ template <int WQ, int TQ, int WR, int TR>
 int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
     p.n_qblocks = (p.n_queries + Cfg::BQ - 1) / Cfg::BQ;
-    // about two resident workgroups per CU, strips a multiple of 8 (one per XCD slot)
-    int64_t want_strips = (512 + p.n_qblocks - 1) / p.n_qblocks;
+    // one resident wave of workgroups (LDS decides how many fit a CU), strips a multiple of 8
+    const int per_cu = (int)((160 * 1024) / Cfg::LDS_BYTES) > 0 ? (int)((160 * 1024) / Cfg::LDS_BYTES) : 1;
+    const int resident = 256 * (per_cu > 4 ? 4 : per_cu);
+    int64_t want_strips = (resident + p.n_qblocks - 1) / p.n_qblocks;
     int64_t max_strips = ceil_div64(p.n_rows, BN);
     if (want_strips > max_strips) want_strips = max_strips;
     if (want_strips < 1) want_strips = 1;
@@ -516,6 +529,11 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
     if (rc) return rc;
     rc = h->cand_count.ensure((size_t)p.n_queries * p.n_strips * sizeof(int32_t));
     if (rc) return rc;
+    rc = h->tau_shared.ensure((size_t)p.n_queries * sizeof(uint32_t));
+    if (rc) return rc;
+    p.tau_shared = (uint32_t*)h->tau_shared.p;
+    // key of -inf: below every real score
+    RAG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.tau_shared, 0x007FFFFF, (size_t)p.n_queries, stream));
     p.scratch = (uint2*)h->scratch.p;
     p.cand = (uint2*)h->cand.p;
     p.cand_count = (int32_t*)h->cand_count.p;
@@ -574,13 +592,17 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     }
     p.cap = (cap + 63) / 64 * 64;
     p.euclid = h->metric == RAG_METRIC_EUCLID;
+    p.debug_row_mod = 0;
+    if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
     int rc;
     if (n_queries <= 32)
         rc = launch_scan<1, 1, 4, 1>(h, p, stream);
     else if (n_queries <= 64)
         rc = launch_scan<1, 2, 4, 1>(h, p, stream);
-    else
+    else if (getenv("RAG_DENSE_WIDE") || n_queries < 256)
         rc = launch_scan<2, 2, 2, 2>(h, p, stream);
+    else
+        rc = launch_scan<4, 2, 2, 2>(h, p, stream);
     if (rc) return rc;
     rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
                              d_out_row, d_out_count, stream);

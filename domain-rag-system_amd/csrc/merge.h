@@ -127,6 +127,11 @@ __global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_ite
         }
     }
     __syncthreads();
+#ifdef RAG_SEL_DEBUG
+    if (tid == 0 || tid == 70 || tid == 200)
+        printf("[merge dbg] q=%d tid=%d n_items=%d K=%d thr pk=%llx mk=%llx pr=%x mr=%x gathered=%d\n", q, tid, n_items, K,
+               (unsigned long long)thr.pk, (unsigned long long)thr.mk, thr.pr, thr.mr, counter[1]);
+#endif
     // rank counting: position = number of selected items that are better
     for (int i = tid; i < K; i += MERGE_NT) {
         const KeyT key = sel_key[i];

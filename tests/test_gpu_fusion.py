@@ -175,6 +175,27 @@ def test_merge_topk_matches_sort():
             assert np.array_equal(s[q, :c[q]], np.asarray([t[0] for t in items], dtype))
 
 
+@pytest.mark.parametrize('k', [1, 10, 16, 100])
+def test_merge_lists_with_a_narrow_score_range(k):
+    """All scores positive and close together: the keys share their high bits, so the radix
+    select starts below the top byte."""
+    import torch
+    import rag_hip
+    rng = np.random.default_rng(k)
+    B, L = 5, 8
+    dev = torch.device('cuda:0')
+    for dtype, lo, span in ((np.float32, 0.05, 0.1), (np.float64, 11.0, 3.0), (np.float32, 0.7, 1e-5)):
+        score = (lo + span * rng.random((B, L, k))).astype(dtype)
+        row = rng.permutation(B * L * k).reshape(B, L, k).astype(np.int64)
+        s, r, c = rag_hip.merge_topk_dev(torch.from_numpy(score).to(dev), torch.from_numpy(row).to(dev), None, k)
+        torch.cuda.synchronize()
+        for q in range(B):
+            items = sorted(zip(score[q].ravel().tolist(), row[q].ravel().tolist()), reverse=True)[:k]
+            assert int(c[q]) == k
+            assert r[q].cpu().tolist() == [int(t[1]) for t in items]
+            assert np.array_equal(s[q].cpu().numpy(), np.asarray([t[0] for t in items], dtype))
+
+
 def test_ce_pack_layout():
     import torch
     import rag_hip
