@@ -20,6 +20,8 @@
 #include "common.h"
 #include "merge.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int BM_NT = 256;
@@ -31,6 +33,8 @@ struct Bm25Params {
     const double* impact;
     const double* idf;
     int64_t n_docs;
+    int64_t vocab;
+    uint32_t* fault;               // RAG_FAULT_* bits of this device (may be null)
     const int32_t* qterms;
     const int32_t* qoff;
     int n_queries;
@@ -43,6 +47,7 @@ struct Bm25Params {
     uint32_t* cand_row;
     int32_t* cand_count;           // [n_queries][n_tiles]
     double* dense_out;             // scores mode: [n_docs]
+    int share_tau;                 // tuning aid: 0 = tiles do not share their thresholds
 };
 
 __global__ void bm25_offsets_kernel(Bm25Params p) {
@@ -53,7 +58,8 @@ __global__ void bm25_offsets_kernel(Bm25Params p) {
     const int tile = (int)(gid - (int64_t)ti * per);
     const int term = p.qterms[ti];
     uint32_t result = 0;
-    if (term >= 0) {
+    if (term >= p.vocab && tile == 0) rag_flag(p.fault, RAG_FAULT_BM25_TERM);
+    if (term >= 0 && term < p.vocab) {
         const int64_t lo0 = p.indptr[term], hi0 = p.indptr[term + 1];
         const uint64_t target = (uint64_t)tile * BM_TILE;
         int64_t lo = lo0, hi = hi0;
@@ -69,7 +75,7 @@ __global__ void bm25_offsets_kernel(Bm25Params p) {
 template <bool SCORES_ONLY>
 __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
     __shared__ double acc[BM_TILE];
-    __shared__ uint32_t sel_lds[RAG_SEL_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t sel_lds[RAG_SEL_LDS_WORDS];
     __shared__ unsigned long long tau_s;
     __shared__ unsigned long long kmin_s;
     __shared__ int count_s[2];
@@ -85,21 +91,31 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
         count_s[0] = 0;
         count_s[1] = 0;
         kmin_s = ~0ull;
-        tau_s = SCORES_ONLY ? 0ull : __hip_atomic_load(&p.tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tau_s = (SCORES_ONLY || !p.share_tau)
+                    ? 0ull : __hip_atomic_load(&p.tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 
-    const int t_begin = p.qoff[q], t_end = p.qoff[q + 1];
+    int t_begin = p.qoff[q], t_end = p.qoff[q + 1];
+    if (t_begin < 0 || t_end > p.n_terms_total) {     // offsets beyond the term array
+        if (tid == 0) rag_flag(p.fault, RAG_FAULT_SEGMENT);
+        t_begin = max(t_begin, 0);
+        t_end = min(t_end, p.n_terms_total);
+    }
     const int per = p.n_tiles + 1;
     for (int ti = t_begin; ti < t_end; ++ti) {
         const int term = p.qterms[ti];
-        if (term < 0) continue;                       // out of vocabulary: contributes nothing
+        if (term < 0 || term >= p.vocab) continue;    // out of vocabulary: contributes nothing
         const int64_t base = p.indptr[term];
         const int64_t lo = base + p.toff[(int64_t)ti * per + tile];
         const int64_t hi = base + p.toff[(int64_t)ti * per + tile + 1];
         const double w = p.idf[term];
         for (int64_t at = lo + tid; at < hi; at += BM_NT) {
-            const int r = (int)((int64_t)p.rows[at] - r0);
+            const int64_t r = (int64_t)p.rows[at] - r0;
+            if (r < 0 || r >= BM_TILE) {               // postings not sorted by row: index is corrupt
+                rag_flag(p.fault, RAG_FAULT_BM25_POSTING);
+                continue;
+            }
             // score += idf * impact, two roundings, no contraction
             acc[r] = __dadd_rn(acc[r], __dmul_rn(w, p.impact[at]));
         }
@@ -127,8 +143,10 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
             unsigned long long key = f64_to_key(acc[i]);
             if (key >= tau) {
                 int at = atomicAdd(&count_s[1], 1);
-                p.cand_key[slot + at] = key;
-                p.cand_row[slot + at] = (uint32_t)(r0 + i);
+                if (at < p.k) {
+                    p.cand_key[slot + at] = key;
+                    p.cand_row[slot + at] = (uint32_t)(r0 + i);
+                }
             }
         }
     } else {
@@ -143,8 +161,10 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
             uint32_t row = (uint32_t)(r0 + i);
             if (sel_pass(thr, key, row)) {
                 int at = atomicAdd(&count_s[1], 1);
-                p.cand_key[slot + at] = key;
-                p.cand_row[slot + at] = row;
+                if (at < p.k) {
+                    p.cand_key[slot + at] = key;
+                    p.cand_row[slot + at] = row;
+                }
                 kmin = min(kmin, (unsigned long long)key);
             }
         }
@@ -152,8 +172,10 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
     }
     __syncthreads();
     if (tid == 0) {
-        p.cand_count[(size_t)q * p.n_tiles + tile] = count_s[1];
-        if (n_pass > p.k) atomicMax(&p.tau[q], kmin_s);
+        if (count_s[1] > p.k) rag_flag(p.fault, RAG_FAULT_BM25_LIST);
+        p.cand_count[(size_t)q * p.n_tiles + tile] = min(count_s[1], p.k);
+        // only an exact selection proves that k documents reach kmin
+        if (p.share_tau && n_pass > p.k && count_s[1] == p.k) atomicMax(&p.tau[q], kmin_s);
     }
 }
 
@@ -251,6 +273,8 @@ int bm25_prepare(rag_bm25_t h, Bm25Params& p, const int32_t* d_qterms, const int
     p.impact = h->impact;
     p.idf = h->idf;
     p.n_docs = h->n_docs;
+    p.vocab = h->vocab;
+    p.fault = rag_fault_word();
     p.qterms = d_qterms;
     p.qoff = d_qoff;
     p.n_queries = n_queries;
@@ -290,6 +314,7 @@ extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const 
     int rc = bm25_prepare(h, p, d_qterms, d_qoff, n_queries, n_terms_total, stream);
     if (rc) return rc;
     p.k = k;
+    p.share_tau = getenv("RAG_BM25_NO_TAU") ? 0 : 1;
     const size_t slots = (size_t)n_queries * p.n_tiles;
     if ((rc = h->tau.ensure((size_t)n_queries * sizeof(unsigned long long)))) return rc;
     if ((rc = h->cand_key.ensure(slots * k * sizeof(uint64_t)))) return rc;
@@ -306,7 +331,7 @@ extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const 
     bm25_tile_kernel<false><<<(unsigned)n_blocks, BM_NT, 0, stream>>>(p);
     RAG_HIP_TRY(hipGetLastError());
     return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, p.n_tiles, k, k, h->row_base,
-                               d_out_score, d_out_row, d_out_count, stream);
+                               d_out_score, d_out_row, d_out_count, p.fault, stream);
 }
 
 #define BM_TRY_OR_CLEAN(expr)                                                                    \

@@ -63,6 +63,16 @@ struct DevBuf {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Device word of the current device that collects RAG_FAULT_* bits (null if it could not be
+// allocated).  Kernels receive it as an argument; a kernel that finds an index read from
+// device data outside its array sets a bit there and carries on with a safe value instead
+// of making the access.
+uint32_t* rag_fault_word();
+
+__device__ __forceinline__ void rag_flag(uint32_t* w, uint32_t bit) {
+    if (w != nullptr) atomicOr(w, bit);
+}
+
 // ---------------------------------------------------------------------------------
 // device side: order-preserving integer keys for floating-point scores
 // (larger key <=> larger score; -0 and +0 map to the same key)
@@ -105,7 +115,8 @@ __device__ __forceinline__ bool sel_pass(const SelThr<KeyT>& t, KeyT key, uint32
     return a > t.pk || (a == t.pk && (row & t.mr) >= t.pr);
 }
 
-// LDS scratch needed by one radix_select group: 256 histogram bins + 8 broadcast words.
+// LDS scratch needed by one radix_select group: 256 histogram bins + 8 broadcast words,
+// 16-byte aligned.
 #define RAG_SEL_LDS_WORDS 264
 
 // NT = threads in the cooperating group: 64 (one wave, other waves of the block may be
@@ -149,9 +160,13 @@ __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
                 if (c < krem && krem <= c + hh[j]) {
-                    bc[0] = (uint32_t)(4 * l + j);  // the digit
-                    bc[1] = c;                      // items strictly above it
-                    bc[2] = hh[j];                  // items in it
+                    // digit, items strictly above it, items in it.  One aligned 16-byte store on
+                    // purpose: written as three dwords the compiler merges them into one
+                    // ds_write_b96, and with that store selections came out a few items short
+                    // (histogram totals of consecutive passes disagreed) whenever a second
+                    // workgroup shared the compute unit (gfx950, ROCm 7.2); with ds_write_b128 or
+                    // three ds_write_b32 they never did.
+                    *reinterpret_cast<uint4*>(bc) = make_uint4((uint32_t)(4 * l + j), c, hh[j], 1u);
                 }
                 c += hh[j];
             }
@@ -200,7 +215,8 @@ __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds
             gsync();
             pick_digit();
             gsync();
-            const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
+            const uint4 pick = *reinterpret_cast<const uint4*>(bc);
+            const uint32_t d = pick.x, above = pick.y, inbin = pick.z;
             t.pk |= (KeyT)d << lo;
             t.mk |= (KeyT)wmask << lo;
             krem -= above;
@@ -220,7 +236,8 @@ __device__ inline SelThr<KeyT> radix_select(Get get, int n, int K, uint32_t* lds
             gsync();
             pick_digit();
             gsync();
-            const uint32_t d = bc[0], above = bc[1], inbin = bc[2];
+            const uint4 pick = *reinterpret_cast<const uint4*>(bc);
+            const uint32_t d = pick.x, above = pick.y, inbin = pick.z;
             t.pr |= d << lo;
             t.mr |= 255u << lo;
             krem -= above;

@@ -46,6 +46,7 @@ struct DenseScanParams {
     uint2* cand;                // [n_queries][n_strips][k]
     int32_t* cand_count;        // [n_queries][n_strips]
     uint32_t* tau_shared;       // [n_queries] key of a lower bound of each query's final K-th score
+    uint32_t* fault;            // RAG_FAULT_* bits of this device (may be null)
     int euclid;
     int debug_row_mod;          // tuning aid: when > 0, row loads wrap at this many rows (results meaningless)
 };
@@ -256,7 +257,10 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
                                 const uint32_t grow = (uint32_t)(trow0 + rl);
                                 if (p.row_mask == nullptr || p.row_mask[grow]) {
                                     int slot = atomicAdd(&cnt_s[ql], 1);
-                                    my_scratch[(size_t)ql * p.cap + slot] = make_uint2(f32_to_key(sc), grow);
+                                    if (slot < p.cap)
+                                        my_scratch[(size_t)ql * p.cap + slot] = make_uint2(f32_to_key(sc), grow);
+                                    else
+                                        rag_flag(p.fault, RAG_FAULT_DENSE_LIST);
                                 }
                             }
                         }
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
                     int b = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     int q = base + b;
-                    int n = cnt_s[q];
+                    int n = min(cnt_s[q], p.cap);
                     uint32_t kmin = wave_compact(my_scratch + (size_t)q * p.cap, n, p.k,
                                                  sel_s + wave * RAG_SEL_LDS_WORDS, lane);
                     if (lane == 0) {
@@ -593,6 +597,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     p.cap = (cap + 63) / 64 * 64;
     p.euclid = h->metric == RAG_METRIC_EUCLID;
     p.debug_row_mod = 0;
+    p.fault = rag_fault_word();
     if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
     int rc;
     if (n_queries <= 32)
@@ -605,7 +610,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         rc = launch_scan<4, 2, 2, 2>(h, p, stream);
     if (rc) return rc;
     rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
-                             d_out_row, d_out_count, stream);
+                             d_out_row, d_out_count, p.fault, stream);
     if (rc) return rc;
     if (p.euclid) {
         euclid_finish_kernel<<<n_queries, 64, 0, stream>>>(d_out_score, d_out_count, d_queries, n_queries, k, h->dim);

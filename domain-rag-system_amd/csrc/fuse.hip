@@ -9,6 +9,8 @@
 #include "common.h"
 #include "merge.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int FUSE_WAVES = 2;                      // queries per workgroup (LDS: 21 KB each)
@@ -18,6 +20,8 @@ struct FuseParams {
     const int64_t* vec_row;  const double* vec_score;  const int32_t* vec_count;  int vec_stride;
     const int64_t* bm_row;   const double* bm_score;  const int32_t* bm_count;   int bm_stride;
     const uint32_t* canon;
+    int64_t n_canon;
+    uint32_t* fault;
     int n_queries, top_k;
     double k_const, vw, bw;
     int32_t* out_pos;  int64_t* out_row;  double* out_score;  int32_t* out_count;
@@ -65,7 +69,12 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
     for (int e = lane; e < n; e += 64) {
         const bool is_vec = e < nv;
         const int64_t row = is_vec ? vrow[e] : brow[e - nv];
-        ids[e] = p.canon ? p.canon[row] : (uint32_t)row;
+        uint32_t id = (uint32_t)row;
+        if (p.canon != nullptr) {
+            if (row >= 0 && row < p.n_canon) id = p.canon[row];
+            else rag_flag(p.fault, RAG_FAULT_FUSE_ROW);     // fuses on its own id
+        }
+        ids[e] = id;
         double c;
         if (!WEIGHTED) {
             const int rank = (is_vec ? e : e - nv) + 1;
@@ -140,14 +149,21 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
 
 // Stable descending order of each pool's scores, cut at top_k: one wave per pool.
 __global__ __launch_bounds__(FUSE_WAVES * 64) void topk_segmented_kernel(const float* __restrict__ score,
+                                                                         int n_scores,
                                                                          const int32_t* __restrict__ seg_off,
                                                                          int n_queries, int top_k,
                                                                          int32_t* __restrict__ out_idx,
-                                                                         int32_t* __restrict__ out_count) {
+                                                                         int32_t* __restrict__ out_count,
+                                                                         uint32_t* fault) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * FUSE_WAVES + w;
     if (q >= n_queries) return;
-    const int b = seg_off[q], n = seg_off[q + 1] - b;
+    const int b = seg_off[q];
+    int n = seg_off[q + 1] - b;
+    if (b < 0 || n < 0 || (int64_t)b + n > n_scores) {   // pool outside the score array: empty
+        if (lane == 0) rag_flag(fault, RAG_FAULT_SEGMENT);
+        n = 0;
+    }
     const int n_out = min(n, top_k);
     int32_t* out = out_idx + (size_t)q * top_k;
     for (int i = n_out + lane; i < top_k; i += 64) out[i] = -1;
@@ -165,31 +181,42 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void topk_segmented_kernel(const f
 
 // One wave per pair: [CLS] query [SEP] chunk [SEP], padded to seq_len.
 __global__ __launch_bounds__(256) void ce_pack_kernel(const int32_t* __restrict__ query_tok,
-                                                      const int64_t* __restrict__ query_off,
+                                                      const int64_t* __restrict__ query_off, int n_queries,
                                                       const int32_t* __restrict__ chunk_tok,
-                                                      const int64_t* __restrict__ chunk_off, int64_t chunk_row_base,
+                                                      const int64_t* __restrict__ chunk_off, int64_t n_chunks,
+                                                      int64_t chunk_row_base,
                                                       const int32_t* __restrict__ pair_query,
                                                       const int64_t* __restrict__ pair_row,
-                                                      const int32_t* __restrict__ pair_slot, int n_pairs, int seq_len,
-                                                      int cls_id, int sep_id, int pad_id, int64_t* __restrict__ ids,
-                                                      int64_t* __restrict__ types, int64_t* __restrict__ mask) {
+                                                      const int32_t* __restrict__ pair_slot, int n_pairs, int n_slots,
+                                                      int seq_len, int cls_id, int sep_id, int pad_id,
+                                                      int64_t* __restrict__ ids, int64_t* __restrict__ types,
+                                                      int64_t* __restrict__ mask, uint32_t* fault) {
     const int lane = threadIdx.x & 63;
     const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pr >= n_pairs) return;
     const int64_t slot = pair_slot ? pair_slot[pr] : pr;
+    if (slot < 0 || slot >= n_slots) {                   // nowhere to write this pair
+        if (lane == 0) rag_flag(fault, RAG_FAULT_CE_PAIR);
+        return;
+    }
     int64_t* oi = ids + slot * seq_len;
     int64_t* ot = types + slot * seq_len;
     int64_t* om = mask + slot * seq_len;
     const int64_t row = pair_row[pr];
-    if (row < 0) {
+    const int64_t lrow = row - chunk_row_base;
+    const int qi = pair_query[pr];
+    const bool bad = row >= 0 && (lrow < 0 || lrow >= n_chunks || qi < 0 || qi >= n_queries);
+    if (bad && lane == 0) rag_flag(fault, RAG_FAULT_CE_PAIR);
+    if (row < 0 || bad) {
         for (int i = lane; i < seq_len; i += 64) { oi[i] = pad_id; ot[i] = 0; om[i] = 0; }
         return;
     }
-    const int qi = pair_query[pr];
     const int64_t qb = query_off[qi];
     int qn = (int)(query_off[qi + 1] - qb);
-    const int64_t cb = chunk_off[row - chunk_row_base];
-    int cn = (int)(chunk_off[row - chunk_row_base + 1] - cb);
+    const int64_t cb = chunk_off[lrow];
+    int cn = (int)(chunk_off[lrow + 1] - cb);
+    qn = max(qn, 0);
+    cn = max(cn, 0);
     qn = min(qn, max(seq_len - 3, 0));
     cn = min(cn, max(seq_len - 3 - qn, 0));
     const int first = 2 + qn;               // [CLS] q.. [SEP]
@@ -208,17 +235,24 @@ __global__ __launch_bounds__(256) void ce_pack_kernel(const int32_t* __restrict_
     }
 }
 
-__global__ void ce_pair_len_kernel(const int64_t* __restrict__ query_off, const int64_t* __restrict__ chunk_off,
+__global__ void ce_pair_len_kernel(const int64_t* __restrict__ query_off, int n_queries,
+                                   const int64_t* __restrict__ chunk_off, int64_t n_chunks,
                                    int64_t chunk_row_base, const int32_t* __restrict__ pair_query,
                                    const int64_t* __restrict__ pair_row, int n_pairs, int max_len,
-                                   int32_t* __restrict__ out_len) {
+                                   int32_t* __restrict__ out_len, uint32_t* fault) {
     const int pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= n_pairs) return;
     const int64_t row = pair_row[pr];
     if (row < 0) { out_len[pr] = 0; return; }
+    const int64_t lrow = row - chunk_row_base;
     const int qi = pair_query[pr];
-    int qn = (int)(query_off[qi + 1] - query_off[qi]);
-    int cn = (int)(chunk_off[row - chunk_row_base + 1] - chunk_off[row - chunk_row_base]);
+    if (lrow < 0 || lrow >= n_chunks || qi < 0 || qi >= n_queries) {
+        rag_flag(fault, RAG_FAULT_CE_PAIR);
+        out_len[pr] = 0;
+        return;
+    }
+    int qn = max((int)(query_off[qi + 1] - query_off[qi]), 0);
+    int cn = max((int)(chunk_off[lrow + 1] - chunk_off[lrow]), 0);
     qn = min(qn, max(max_len - 3, 0));
     cn = min(cn, max(max_len - 3 - qn, 0));
     out_len[pr] = qn + cn + 3;
@@ -238,9 +272,9 @@ int check_fuse_args(const char* who, const void* vec_row, const void* bm_row, in
 
 extern "C" int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_count, int32_t vec_stride,
                                 const int64_t* d_bm_row, const int32_t* d_bm_count, int32_t bm_stride,
-                                const uint32_t* d_canon, int32_t n_queries, int32_t top_k, double k_const,
-                                int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score, int32_t* d_out_count,
-                                void* stream) {
+                                const uint32_t* d_canon, int64_t n_canon, int32_t n_queries, int32_t top_k,
+                                double k_const, int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
+                                int32_t* d_out_count, void* stream) {
     int rc = check_fuse_args("rag_fuse_rrf", d_vec_row, d_bm_row, vec_stride, bm_stride, n_queries, top_k, d_out_pos,
                              d_out_row, d_out_score, d_out_count);
     if (rc) return rc;
@@ -249,7 +283,8 @@ extern "C" int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_c
     memset(&p, 0, sizeof(p));
     p.vec_row = d_vec_row; p.vec_count = vec_stride ? d_vec_count : nullptr; p.vec_stride = vec_stride;
     p.bm_row = d_bm_row; p.bm_count = bm_stride ? d_bm_count : nullptr; p.bm_stride = bm_stride;
-    p.canon = d_canon; p.n_queries = n_queries; p.top_k = top_k; p.k_const = k_const;
+    p.canon = n_canon > 0 ? d_canon : nullptr; p.n_canon = n_canon; p.fault = rag_fault_word();
+    p.n_queries = n_queries; p.top_k = top_k; p.k_const = k_const;
     p.out_pos = d_out_pos; p.out_row = d_out_row; p.out_score = d_out_score; p.out_count = d_out_count;
     fuse_kernel<false><<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, (hipStream_t)stream>>>(p);
     RAG_HIP_TRY(hipGetLastError());
@@ -259,7 +294,8 @@ extern "C" int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_c
 extern "C" int rag_fuse_weighted_dev(const int64_t* d_vec_row, const double* d_vec_score, const int32_t* d_vec_count,
                                      int32_t vec_stride, const int64_t* d_bm_row, const double* d_bm_score,
                                      const int32_t* d_bm_count, int32_t bm_stride, const uint32_t* d_canon,
-                                     int32_t n_queries, int32_t top_k, double vector_weight, double bm25_weight,
+                                     int64_t n_canon, int32_t n_queries, int32_t top_k, double vector_weight,
+                                     double bm25_weight,
                                      int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
                                      int32_t* d_out_count, void* stream) {
     int rc = check_fuse_args("rag_fuse_weighted", d_vec_row, d_bm_row, vec_stride, bm_stride, n_queries, top_k,
@@ -272,7 +308,8 @@ extern "C" int rag_fuse_weighted_dev(const int64_t* d_vec_row, const double* d_v
     memset(&p, 0, sizeof(p));
     p.vec_row = d_vec_row; p.vec_score = d_vec_score; p.vec_count = vec_stride ? d_vec_count : nullptr; p.vec_stride = vec_stride;
     p.bm_row = d_bm_row; p.bm_score = d_bm_score; p.bm_count = bm_stride ? d_bm_count : nullptr; p.bm_stride = bm_stride;
-    p.canon = d_canon; p.n_queries = n_queries; p.top_k = top_k; p.vw = vector_weight; p.bw = bm25_weight;
+    p.canon = n_canon > 0 ? d_canon : nullptr; p.n_canon = n_canon; p.fault = rag_fault_word();
+    p.n_queries = n_queries; p.top_k = top_k; p.vw = vector_weight; p.bw = bm25_weight;
     p.out_pos = d_out_pos; p.out_row = d_out_row; p.out_score = d_out_score; p.out_count = d_out_count;
     fuse_kernel<true><<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, (hipStream_t)stream>>>(p);
     RAG_HIP_TRY(hipGetLastError());
@@ -331,11 +368,11 @@ int fuse_host(bool weighted, const int64_t* vec_row, const double* vec_score, co
     if ((rc = st.up((void**)&d_os, nullptr, nq * top_k * sizeof(double)))) return rc;
     if ((rc = st.up((void**)&d_oc, nullptr, nq * sizeof(int32_t)))) return rc;
     if (weighted)
-        rc = rag_fuse_weighted_dev(d_vr, d_vs, d_vc, vec_stride, d_br, d_bs, d_bc, bm_stride, d_canon, n_queries, top_k,
-                                   a, b, d_op, d_or, d_os, d_oc, nullptr);
+        rc = rag_fuse_weighted_dev(d_vr, d_vs, d_vc, vec_stride, d_br, d_bs, d_bc, bm_stride, d_canon,
+                                   d_canon ? n_canon : 0, n_queries, top_k, a, b, d_op, d_or, d_os, d_oc, nullptr);
     else
-        rc = rag_fuse_rrf_dev(d_vr, d_vc, vec_stride, d_br, d_bc, bm_stride, d_canon, n_queries, top_k, a, d_op, d_or,
-                              d_os, d_oc, nullptr);
+        rc = rag_fuse_rrf_dev(d_vr, d_vc, vec_stride, d_br, d_bc, bm_stride, d_canon, d_canon ? n_canon : 0, n_queries,
+                              top_k, a, d_op, d_or, d_os, d_oc, nullptr);
     if (rc) return rc;
     if ((rc = st.down(out_pos, d_op, nq * top_k * sizeof(int32_t)))) return rc;
     if ((rc = st.down(out_row, d_or, nq * top_k * sizeof(int64_t)))) return rc;
@@ -368,14 +405,16 @@ extern "C" int rag_fuse_weighted(const int64_t* vec_row, const double* vec_score
                      n_canon, n_queries, top_k, vector_weight, bm25_weight, out_pos, out_row, out_score, out_count);
 }
 
-extern "C" int rag_topk_segmented_dev(const float* d_score, const int32_t* d_seg_off, int32_t n_queries, int32_t top_k,
-                                      int32_t* d_out_idx, int32_t* d_out_count, void* stream) {
-    RAG_REQUIRE(n_queries >= 0 && top_k >= 1 && top_k <= RAG_MAX_K, RAG_ELIMIT, "rag_topk_segmented: need 1 <= top_k <= %d",
-                RAG_MAX_K);
+extern "C" int rag_topk_segmented_dev(const float* d_score, int32_t n_scores, const int32_t* d_seg_off,
+                                      int32_t n_queries, int32_t top_k, int32_t* d_out_idx, int32_t* d_out_count,
+                                      void* stream) {
+    RAG_REQUIRE(n_queries >= 0 && n_scores >= 0 && top_k >= 1 && top_k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_topk_segmented: need 1 <= top_k <= %d", RAG_MAX_K);
     if (n_queries == 0) return RAG_OK;
-    RAG_REQUIRE(d_score && d_seg_off && d_out_idx && d_out_count, RAG_EINVAL, "rag_topk_segmented: null pointer");
+    RAG_REQUIRE((d_score || n_scores == 0) && d_seg_off && d_out_idx && d_out_count, RAG_EINVAL,
+                "rag_topk_segmented: null pointer");
     topk_segmented_kernel<<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, (hipStream_t)stream>>>(
-        d_score, d_seg_off, n_queries, top_k, d_out_idx, d_out_count);
+        d_score, n_scores, d_seg_off, n_queries, top_k, d_out_idx, d_out_count, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -396,37 +435,44 @@ extern "C" int rag_topk_segmented(const float* score, const int32_t* seg_off, in
     if ((rc = st.up((void**)&d_o, seg_off, (size_t)(n_queries + 1) * sizeof(int32_t)))) return rc;
     if ((rc = st.up((void**)&d_i, nullptr, (size_t)n_queries * top_k * sizeof(int32_t)))) return rc;
     if ((rc = st.up((void**)&d_c, nullptr, (size_t)n_queries * sizeof(int32_t)))) return rc;
-    if ((rc = rag_topk_segmented_dev(d_s, d_o, n_queries, top_k, d_i, d_c, nullptr))) return rc;
+    if ((rc = rag_topk_segmented_dev(d_s, n, d_o, n_queries, top_k, d_i, d_c, nullptr))) return rc;
     if ((rc = st.down(out_idx, d_i, (size_t)n_queries * top_k * sizeof(int32_t)))) return rc;
     return st.down(out_count, d_c, (size_t)n_queries * sizeof(int32_t));
 }
 
-extern "C" int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off, const int32_t* d_chunk_tok,
-                               const int64_t* d_chunk_off, int64_t chunk_row_base, const int32_t* d_pair_query,
-                               const int64_t* d_pair_row, const int32_t* d_pair_slot, int32_t n_pairs, int32_t seq_len,
+extern "C" int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off, int32_t n_queries,
+                               const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t n_chunks,
+                               int64_t chunk_row_base, const int32_t* d_pair_query, const int64_t* d_pair_row,
+                               const int32_t* d_pair_slot, int32_t n_pairs, int32_t n_slots, int32_t seq_len,
                                int32_t cls_id, int32_t sep_id, int32_t pad_id, int64_t* d_input_ids,
                                int64_t* d_token_type_ids, int64_t* d_attention_mask, void* stream) {
     RAG_REQUIRE(n_pairs >= 0 && seq_len >= 3, RAG_EINVAL, "rag_ce_pack: need n_pairs >= 0 and seq_len >= 3");
+    RAG_REQUIRE(n_queries >= 0 && n_chunks >= 0 && n_slots >= 0 && (d_pair_slot || n_slots >= n_pairs), RAG_EINVAL,
+                "rag_ce_pack: negative size, or fewer slots than pairs");
     if (n_pairs == 0) return RAG_OK;
     RAG_REQUIRE(d_query_tok && d_query_off && d_chunk_tok && d_chunk_off && d_pair_query && d_pair_row && d_input_ids &&
                     d_token_type_ids && d_attention_mask,
                 RAG_EINVAL, "rag_ce_pack: null pointer");
     ce_pack_kernel<<<(n_pairs + 3) / 4, 256, 0, (hipStream_t)stream>>>(
-        d_query_tok, d_query_off, d_chunk_tok, d_chunk_off, chunk_row_base, d_pair_query, d_pair_row, d_pair_slot,
-        n_pairs, seq_len, cls_id, sep_id, pad_id, d_input_ids, d_token_type_ids, d_attention_mask);
+        d_query_tok, d_query_off, n_queries, d_chunk_tok, d_chunk_off, n_chunks, chunk_row_base, d_pair_query,
+        d_pair_row, d_pair_slot, n_pairs, n_slots, seq_len, cls_id, sep_id, pad_id, d_input_ids, d_token_type_ids,
+        d_attention_mask, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
-extern "C" int rag_ce_pair_len_dev(const int64_t* d_query_off, const int64_t* d_chunk_off, int64_t chunk_row_base,
-                                   const int32_t* d_pair_query, const int64_t* d_pair_row, int32_t n_pairs,
-                                   int32_t max_len, int32_t* d_out_len, void* stream) {
+extern "C" int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int64_t* d_chunk_off,
+                                   int64_t n_chunks, int64_t chunk_row_base, const int32_t* d_pair_query,
+                                   const int64_t* d_pair_row, int32_t n_pairs, int32_t max_len, int32_t* d_out_len,
+                                   void* stream) {
     RAG_REQUIRE(n_pairs >= 0 && max_len >= 3, RAG_EINVAL, "rag_ce_pair_len: need n_pairs >= 0 and max_len >= 3");
+    RAG_REQUIRE(n_queries >= 0 && n_chunks >= 0, RAG_EINVAL, "rag_ce_pair_len: negative size");
     if (n_pairs == 0) return RAG_OK;
     RAG_REQUIRE(d_query_off && d_chunk_off && d_pair_query && d_pair_row && d_out_len, RAG_EINVAL,
                 "rag_ce_pair_len: null pointer");
     ce_pair_len_kernel<<<(n_pairs + 255) / 256, 256, 0, (hipStream_t)stream>>>(
-        d_query_off, d_chunk_off, chunk_row_base, d_pair_query, d_pair_row, n_pairs, max_len, d_out_len);
+        d_query_off, n_queries, d_chunk_off, n_chunks, chunk_row_base, d_pair_query, d_pair_row, n_pairs, max_len,
+        d_out_len, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -443,7 +489,7 @@ extern "C" int rag_merge_topk_f32_dev(const float* d_score, const int64_t* d_row
     ragmerge::ListF32Src src{d_score, d_row, d_count, n_lists, k_in, smaller_is_better ? 1 : 0};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
                        (hipStream_t)stream, src, n_lists * k_in, k_out, (int64_t)0, smaller_is_better ? 1 : 0,
-                       d_out_score, d_out_row, d_out_count);
+                       d_out_score, d_out_row, d_out_count, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -458,7 +504,7 @@ extern "C" int rag_merge_topk_f64_dev(const double* d_score, const int64_t* d_ro
     ragmerge::ListF64Src src{d_score, d_row, d_count, n_lists, k_in};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF64Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
                        (hipStream_t)stream, src, n_lists * k_in, k_out, (int64_t)0, 0, d_out_score, d_out_row,
-                       d_out_count);
+                       d_out_count, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -474,7 +520,40 @@ void rag_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* rag_last_error(void) { return g_err; }
-extern "C" int rag_version(void) { return 100; }
+extern "C" int rag_version(void) { return 101; }
+
+// one fault word per device, allocated on first use and kept for the life of the process
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_fault_mu;
+uint32_t* g_fault[MAX_DEVICES] = {};
+}  // namespace
+
+uint32_t* rag_fault_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    if (g_fault[dev] == nullptr) {
+        uint32_t* w = nullptr;
+        if (hipMalloc((void**)&w, 256) != hipSuccess) return nullptr;
+        if (hipMemset(w, 0, 256) != hipSuccess) {
+            (void)hipFree(w);
+            return nullptr;
+        }
+        g_fault[dev] = w;
+    }
+    return g_fault[dev];
+}
+
+extern "C" int rag_fault_flags(uint32_t* out_flags, int32_t clear) {
+    RAG_REQUIRE(out_flags != nullptr, RAG_EINVAL, "rag_fault_flags: null pointer");
+    uint32_t* w = rag_fault_word();
+    RAG_REQUIRE(w != nullptr, RAG_ENOMEM, "rag_fault_flags: the fault word could not be allocated");
+    RAG_HIP_TRY(hipDeviceSynchronize());
+    RAG_HIP_TRY(hipMemcpy(out_flags, w, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (clear) RAG_HIP_TRY(hipMemset(w, 0, sizeof(uint32_t)));
+    return RAG_OK;
+}
 
 extern "C" int rag_init(int device) {
     int n = 0;
@@ -491,5 +570,6 @@ extern "C" int rag_init(int device) {
         rag_set_error("rag_init: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
         return RAG_ENODEV;
     }
+    RAG_REQUIRE(rag_fault_word() != nullptr, RAG_ENOMEM, "rag_init: the fault word could not be allocated");
     return RAG_OK;
 }

@@ -5,7 +5,9 @@
 
 #include "common.h"
 
+// internal linkage: every translation unit that includes this header gets kernels of its own
 namespace ragmerge {
+namespace {
 
 constexpr int MERGE_NT = 256;
 
@@ -87,10 +89,11 @@ template <typename Src>
 __global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_items, int k_out, int64_t row_base,
                                                               int invert,
                                                               typename ScoreOf<typename Src::key_t>::type* out_score,
-                                                              int64_t* out_row, int32_t* out_count) {
+                                                              int64_t* out_row, int32_t* out_count,
+                                                              uint32_t* fault) {
     typedef typename Src::key_t KeyT;
     typedef typename ScoreOf<KeyT>::type ScoreT;
-    __shared__ uint32_t sel_lds[RAG_SEL_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t sel_lds[RAG_SEL_LDS_WORDS];
     __shared__ KeyT sel_key[RAG_MAX_K];
     __shared__ uint32_t sel_row[RAG_MAX_K];
     __shared__ int counter[2];
@@ -127,17 +130,23 @@ __global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_ite
         }
     }
     __syncthreads();
-#ifdef RAG_SEL_DEBUG
-    if (tid == 0 || tid == 70 || tid == 200)
-        printf("[merge dbg] q=%d tid=%d n_items=%d K=%d thr pk=%llx mk=%llx pr=%x mr=%x gathered=%d\n", q, tid, n_items, K,
-               (unsigned long long)thr.pk, (unsigned long long)thr.mk, thr.pr, thr.mr, counter[1]);
-#endif
+    // the selection yields exactly K entries; anything else is an internal error: report it
+    // and emit only entries that were really gathered
+    const int got = min(counter[1], RAG_MAX_K);
+    const int kept = min(got, K);
+    if (got != K) {
+        if (tid == 0) {
+            rag_flag(fault, RAG_FAULT_MERGE_SHORT);
+            out_count[q] = kept;
+        }
+        for (int i = kept + tid; i < K; i += MERGE_NT) { os[i] = ScoreOf<KeyT>::empty(); orow[i] = -1; }
+    }
     // rank counting: position = number of selected items that are better
-    for (int i = tid; i < K; i += MERGE_NT) {
+    for (int i = tid; i < kept; i += MERGE_NT) {
         const KeyT key = sel_key[i];
         const uint32_t row = sel_row[i];
         int rank = 0;
-        for (int j = 0; j < K; ++j) {
+        for (int j = 0; j < kept; ++j) {
             KeyT kj = sel_key[j];
             uint32_t rj = sel_row[j];
             rank += (kj > key || (kj == key && rj > row)) ? 1 : 0;
@@ -147,24 +156,25 @@ __global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_ite
     }
 }
 
+}  // namespace
 }  // namespace ragmerge
 
 static inline int launch_merge_cand32(const uint2* cand, const int32_t* count, int n_queries, int n_lists, int k_in,
                                       int k_out, int64_t row_base, float* out_score, int64_t* out_row,
-                                      int32_t* out_count, hipStream_t stream) {
+                                      int32_t* out_count, uint32_t* fault, hipStream_t stream) {
     ragmerge::Cand32Src src{cand, count, n_lists, k_in};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::Cand32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count);
+                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count, fault);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
 static inline int launch_merge_cand64(const uint64_t* key, const uint32_t* row, const int32_t* count, int n_queries,
                                       int n_lists, int k_in, int k_out, int64_t row_base, double* out_score,
-                                      int64_t* out_row, int32_t* out_count, hipStream_t stream) {
+                                      int64_t* out_row, int32_t* out_count, uint32_t* fault, hipStream_t stream) {
     ragmerge::Cand64Src src{key, row, count, n_lists, k_in};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::Cand64Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count);
+                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count, fault);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

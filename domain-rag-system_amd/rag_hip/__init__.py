@@ -31,6 +31,7 @@ SIGNATURES = {
     'rag_init': (_i32, [_i32]),
     'rag_last_error': (C.c_char_p, []),
     'rag_version': (_i32, []),
+    'rag_fault_flags': (_i32, [C.POINTER(C.c_uint32), _i32]),
     'rag_dense_create': (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
     'rag_dense_destroy': (_i32, [_vp]),
     'rag_dense_rows': (_i64, [_vp]),
@@ -48,17 +49,18 @@ SIGNATURES = {
     'rag_bm25_scores': (_i32, [_vp, _vp, _i32, _vp]),
     'rag_merge_topk_f32_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'rag_merge_topk_f64_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
-    'rag_fuse_rrf_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp]),
-    'rag_fuse_weighted_dev': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f64, _f64,
+    'rag_fuse_rrf_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp, _vp, _vp, _vp,
+                                _vp]),
+    'rag_fuse_weighted_dev': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _f64,
                                      _vp, _vp, _vp, _vp, _vp]),
     'rag_fuse_rrf': (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     'rag_fuse_weighted': (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _f64, _f64,
                                  _vp, _vp, _vp, _vp]),
-    'rag_topk_segmented_dev': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'rag_topk_segmented_dev': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'rag_topk_segmented': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
-    'rag_ce_pack_dev': (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                               _vp, _vp, _vp, _vp]),
-    'rag_ce_pair_len_dev': (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'rag_ce_pack_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                               _i32, _vp, _vp, _vp, _vp]),
+    'rag_ce_pair_len_dev': (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None
@@ -127,13 +129,40 @@ def _np(a, dtype):
     return a, a.ctypes.data
 
 
-def _ptr(t):
-    """Device pointer of a torch tensor (or None)."""
+def _ptr(t, dtype=None):
+    """Device pointer of a torch tensor (or None); the kernels read raw memory, so layout,
+    element type and placement are checked here."""
     if t is None:
         return None
+    if not t.is_cuda:
+        raise ValueError("rag_hip device entry points need tensors on the GPU")
     if not t.is_contiguous():
         raise ValueError("device tensors passed to rag_hip must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"rag_hip expected a {dtype} tensor, got {t.dtype}")
     return t.data_ptr()
+
+
+FAULT_NAMES = {1: 'dense candidate list overflow', 2: 'merge selection short', 4: 'bm25 tile list overflow',
+               8: 'bm25 posting outside its tile', 16: 'bm25 term id beyond the vocabulary',
+               32: 'fusion row outside the canon table', 64: 'cross-encoder pair out of range',
+               128: 'segment offsets out of range'}
+
+
+def fault_flags(clear=True):
+    """RAG_FAULT_* bits the kernels raised on the current device since the last clear
+    (synchronises the device); 0 means every device-side check held."""
+    out = C.c_uint32(0)
+    check(lib().rag_fault_flags(C.byref(out), 1 if clear else 0), 'rag_fault_flags')
+    return int(out.value)
+
+
+def check_faults():
+    """Raise if any device-side check failed since the last clear."""
+    bits = fault_flags(clear=True)
+    if bits:
+        names = [n for b, n in FAULT_NAMES.items() if bits & b]
+        raise RagHipError(f"device-side consistency checks failed (flags {bits:#x}): " + '; '.join(names))
 
 
 def _stream():
@@ -210,8 +239,13 @@ class DenseIndex:
                    torch.empty((b, k), dtype=torch.int64, device=queries.device),
                    torch.empty((b,), dtype=torch.int32, device=queries.device))
         score, row, cnt = out
-        check(lib().rag_dense_search_dev(self._h, _ptr(queries), b, int(k), _ptr(row_mask), _ptr(score), _ptr(row),
-                                         _ptr(cnt), _stream()), 'rag_dense_search_dev')
+        if row_mask is not None and row_mask.shape != (self.n_rows,):
+            raise ValueError("row_mask must have one byte per local row")
+        if tuple(score.shape) != (b, k) or tuple(row.shape) != (b, k) or tuple(cnt.shape) != (b,):
+            raise ValueError("output tensors must be [B, k], [B, k], [B]")
+        check(lib().rag_dense_search_dev(self._h, _ptr(queries, torch.float32), b, int(k), _ptr(row_mask, torch.uint8),
+                                         _ptr(score, torch.float32), _ptr(row, torch.int64), _ptr(cnt, torch.int32),
+                                         _stream()), 'rag_dense_search_dev')
         return score, row, cnt
 
     def profile(self, enable=True):
@@ -238,9 +272,11 @@ class DenseIndex:
     def rescore_dev(self, queries, cand_rows):
         import torch
         b, m = cand_rows.shape
+        if tuple(queries.shape) != (b, self.dim):
+            raise ValueError("queries must be float32 [B, dim] with one row per candidate list")
         out = torch.empty((b, m), dtype=torch.float32, device=queries.device)
-        check(lib().rag_dense_rescore_dev(self._h, _ptr(queries), b, _ptr(cand_rows), m, _ptr(out), _stream()),
-              'rag_dense_rescore_dev')
+        check(lib().rag_dense_rescore_dev(self._h, _ptr(queries, torch.float32), b, _ptr(cand_rows, torch.int64), m,
+                                          _ptr(out), _stream()), 'rag_dense_rescore_dev')
         return out
 
 
@@ -298,8 +334,13 @@ class Bm25Index:
                    torch.empty((b, k), dtype=torch.int64, device=qoff.device),
                    torch.empty((b,), dtype=torch.int32, device=qoff.device))
         score, row, cnt = out
-        check(lib().rag_bm25_search_dev(self._h, _ptr(qterms), _ptr(qoff), b, int(n_terms_total), int(k), _ptr(score),
-                                        _ptr(row), _ptr(cnt), _stream()), 'rag_bm25_search_dev')
+        if int(n_terms_total) > qterms.shape[0]:
+            raise ValueError("n_terms_total exceeds the term array")
+        if tuple(score.shape) != (b, k) or tuple(row.shape) != (b, k) or tuple(cnt.shape) != (b,):
+            raise ValueError("output tensors must be [B, k], [B, k], [B]")
+        check(lib().rag_bm25_search_dev(self._h, _ptr(qterms, torch.int32), _ptr(qoff, torch.int32), b,
+                                        int(n_terms_total), int(k), _ptr(score, torch.float64), _ptr(row, torch.int64),
+                                        _ptr(cnt, torch.int32), _stream()), 'rag_bm25_search_dev')
         return score, row, cnt
 
     def scores(self, query_terms):
@@ -361,6 +402,13 @@ def fuse_weighted(vec_rows, vec_scores, bm_rows, bm_scores, top_k, vector_weight
     return pos, row, score, cnt
 
 
+def _check_lists(vec_row, vec_cnt, bm_row, bm_cnt):
+    b = vec_row.shape[0]
+    if vec_row.dim() != 2 or bm_row.dim() != 2 or bm_row.shape[0] != b or tuple(vec_cnt.shape) != (b,) \
+            or tuple(bm_cnt.shape) != (b,):
+        raise ValueError("fusion inputs must be [B, stride] row tensors with [B] counts")
+
+
 def fuse_rrf_dev(vec_row, vec_cnt, bm_row, bm_cnt, top_k, canon=None, k_const=60.0):
     import torch
     b = vec_row.shape[0]
@@ -369,9 +417,12 @@ def fuse_rrf_dev(vec_row, vec_cnt, bm_row, bm_cnt, top_k, canon=None, k_const=60
     row = torch.empty((b, top_k), dtype=torch.int64, device=dev)
     score = torch.empty((b, top_k), dtype=torch.float64, device=dev)
     cnt = torch.empty((b,), dtype=torch.int32, device=dev)
-    check(lib().rag_fuse_rrf_dev(_ptr(vec_row), _ptr(vec_cnt), vec_row.shape[1], _ptr(bm_row), _ptr(bm_cnt),
-                                 bm_row.shape[1], _ptr(canon), b, int(top_k), float(k_const), _ptr(pos), _ptr(row),
-                                 _ptr(score), _ptr(cnt), _stream()), 'rag_fuse_rrf_dev')
+    _check_lists(vec_row, vec_cnt, bm_row, bm_cnt)
+    check(lib().rag_fuse_rrf_dev(_ptr(vec_row, torch.int64), _ptr(vec_cnt, torch.int32), vec_row.shape[1],
+                                 _ptr(bm_row, torch.int64), _ptr(bm_cnt, torch.int32), bm_row.shape[1],
+                                 _ptr(canon, torch.uint32), 0 if canon is None else canon.shape[0], b, int(top_k),
+                                 float(k_const), _ptr(pos), _ptr(row), _ptr(score), _ptr(cnt), _stream()),
+          'rag_fuse_rrf_dev')
     return pos, row, score, cnt
 
 
@@ -384,8 +435,13 @@ def fuse_weighted_dev(vec_row, vec_score, vec_cnt, bm_row, bm_score, bm_cnt, top
     row = torch.empty((b, top_k), dtype=torch.int64, device=dev)
     score = torch.empty((b, top_k), dtype=torch.float64, device=dev)
     cnt = torch.empty((b,), dtype=torch.int32, device=dev)
-    check(lib().rag_fuse_weighted_dev(_ptr(vec_row), _ptr(vec_score), _ptr(vec_cnt), vec_row.shape[1], _ptr(bm_row),
-                                      _ptr(bm_score), _ptr(bm_cnt), bm_row.shape[1], _ptr(canon), b, int(top_k),
+    _check_lists(vec_row, vec_cnt, bm_row, bm_cnt)
+    if vec_score.shape != vec_row.shape or bm_score.shape != bm_row.shape:
+        raise ValueError("score tensors must have the shape of their row tensors")
+    check(lib().rag_fuse_weighted_dev(_ptr(vec_row, torch.int64), _ptr(vec_score, torch.float64),
+                                      _ptr(vec_cnt, torch.int32), vec_row.shape[1], _ptr(bm_row, torch.int64),
+                                      _ptr(bm_score, torch.float64), _ptr(bm_cnt, torch.int32), bm_row.shape[1],
+                                      _ptr(canon, torch.uint32), 0 if canon is None else canon.shape[0], b, int(top_k),
                                       float(vector_weight), float(bm25_weight), _ptr(pos), _ptr(row), _ptr(score),
                                       _ptr(cnt), _stream()), 'rag_fuse_weighted_dev')
     return pos, row, score, cnt
@@ -407,8 +463,8 @@ def topk_segmented_dev(scores, seg_off, top_k):
     b = seg_off.shape[0] - 1
     idx = torch.empty((b, top_k), dtype=torch.int32, device=scores.device)
     cnt = torch.empty((b,), dtype=torch.int32, device=scores.device)
-    check(lib().rag_topk_segmented_dev(_ptr(scores), _ptr(seg_off), b, int(top_k), _ptr(idx), _ptr(cnt), _stream()),
-          'rag_topk_segmented_dev')
+    check(lib().rag_topk_segmented_dev(_ptr(scores, torch.float32), scores.numel(), _ptr(seg_off, torch.int32), b,
+                                       int(top_k), _ptr(idx), _ptr(cnt), _stream()), 'rag_topk_segmented_dev')
     return idx, cnt
 
 
@@ -417,16 +473,20 @@ def merge_topk_dev(score, row, count, k_out, smaller_is_better=False):
     import torch
     b, nl, kin = score.shape
     dev = score.device
+    if tuple(row.shape) != (b, nl, kin) or (count is not None and tuple(count.shape) != (b, nl)):
+        raise ValueError("merge inputs must be [B, L, k_in] scores and rows with [B, L] counts")
     out_s = torch.empty((b, k_out), dtype=score.dtype, device=dev)
     out_r = torch.empty((b, k_out), dtype=torch.int64, device=dev)
     out_c = torch.empty((b,), dtype=torch.int32, device=dev)
     if score.dtype == torch.float32:
-        check(lib().rag_merge_topk_f32_dev(_ptr(score), _ptr(row), _ptr(count), b, nl, kin, int(k_out),
+        check(lib().rag_merge_topk_f32_dev(_ptr(score), _ptr(row, torch.int64), _ptr(count, torch.int32), b, nl, kin,
+                                           int(k_out),
                                            1 if smaller_is_better else 0, _ptr(out_s), _ptr(out_r), _ptr(out_c),
                                            _stream()), 'rag_merge_topk_f32_dev')
     elif score.dtype == torch.float64:
-        check(lib().rag_merge_topk_f64_dev(_ptr(score), _ptr(row), _ptr(count), b, nl, kin, int(k_out), _ptr(out_s),
-                                           _ptr(out_r), _ptr(out_c), _stream()), 'rag_merge_topk_f64_dev')
+        check(lib().rag_merge_topk_f64_dev(_ptr(score), _ptr(row, torch.int64), _ptr(count, torch.int32), b, nl, kin,
+                                           int(k_out), _ptr(out_s), _ptr(out_r), _ptr(out_c), _stream()),
+              'rag_merge_topk_f64_dev')
     else:
         raise ValueError("scores must be float32 or float64")
     return out_s, out_r, out_c
@@ -450,9 +510,13 @@ def topk_stable_f64(scores, top_k):
 def ce_pair_len_dev(query_off, chunk_off, chunk_row_base, pair_query, pair_row, max_len):
     import torch
     n = pair_row.shape[0]
+    if tuple(pair_query.shape) != (n,):
+        raise ValueError("pair_query and pair_row must have one entry per pair")
     out = torch.empty((n,), dtype=torch.int32, device=pair_row.device)
-    check(lib().rag_ce_pair_len_dev(_ptr(query_off), _ptr(chunk_off), int(chunk_row_base), _ptr(pair_query),
-                                    _ptr(pair_row), n, int(max_len), _ptr(out), _stream()), 'rag_ce_pair_len_dev')
+    check(lib().rag_ce_pair_len_dev(_ptr(query_off, torch.int64), query_off.shape[0] - 1, _ptr(chunk_off, torch.int64),
+                                    chunk_off.shape[0] - 1, int(chunk_row_base), _ptr(pair_query, torch.int32),
+                                    _ptr(pair_row, torch.int64), n, int(max_len), _ptr(out), _stream()),
+          'rag_ce_pair_len_dev')
     return out
 
 
@@ -463,8 +527,12 @@ def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair
     ids = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
     types = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
     mask = torch.empty((n_slots, seq_len), dtype=torch.int64, device=dev)
-    check(lib().rag_ce_pack_dev(_ptr(query_tok), _ptr(query_off), _ptr(chunk_tok), _ptr(chunk_off),
-                                int(chunk_row_base), _ptr(pair_query), _ptr(pair_row), _ptr(pair_slot),
-                                pair_row.shape[0], int(seq_len), int(cls_id), int(sep_id), int(pad_id), _ptr(ids),
-                                _ptr(types), _ptr(mask), _stream()), 'rag_ce_pack_dev')
+    n = pair_row.shape[0]
+    if tuple(pair_query.shape) != (n,) or (pair_slot is not None and tuple(pair_slot.shape) != (n,)):
+        raise ValueError("pair_query, pair_row and pair_slot must have one entry per pair")
+    check(lib().rag_ce_pack_dev(_ptr(query_tok, torch.int32), _ptr(query_off, torch.int64), query_off.shape[0] - 1,
+                                _ptr(chunk_tok, torch.int32), _ptr(chunk_off, torch.int64), chunk_off.shape[0] - 1,
+                                int(chunk_row_base), _ptr(pair_query, torch.int32), _ptr(pair_row, torch.int64),
+                                _ptr(pair_slot, torch.int32), n, int(n_slots), int(seq_len), int(cls_id), int(sep_id),
+                                int(pad_id), _ptr(ids), _ptr(types), _ptr(mask), _stream()), 'rag_ce_pack_dev')
     return ids, types, mask

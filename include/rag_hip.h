@@ -61,6 +61,23 @@ int rag_init(int device);
 const char* rag_last_error(void);
 int rag_version(void);
 
+/* Device-side consistency checks (no counterpart in the reference).  No kernel indexes memory
+ * with an unchecked value that it read from device data (row ids, term ids, offsets, list
+ * lengths): a value outside its array sets one of these bits in a per-device word and the
+ * kernel carries on with a safe substitute (the entry is skipped or treated as empty), so bad
+ * input or an internal error yields flagged results instead of a GPU memory fault.
+ * rag_fault_flags synchronises the current device, returns the bits collected since the last
+ * clear (0 = every check held) and clears them when `clear` is non-zero.                 */
+#define RAG_FAULT_DENSE_LIST    1u  /* dense scan: a candidate list outgrew its capacity     */
+#define RAG_FAULT_MERGE_SHORT   2u  /* list merge: selection did not yield exactly k entries  */
+#define RAG_FAULT_BM25_LIST     4u  /* BM25 scan: a tile selected more than k documents       */
+#define RAG_FAULT_BM25_POSTING  8u  /* BM25 scan: a posting's row lies outside its tile       */
+#define RAG_FAULT_BM25_TERM    16u  /* BM25: query term id >= vocabulary size                 */
+#define RAG_FAULT_FUSE_ROW     32u  /* fusion: row id outside the canon table                 */
+#define RAG_FAULT_CE_PAIR      64u  /* pair packing: query, chunk row or slot out of range    */
+#define RAG_FAULT_SEGMENT     128u  /* segmented top-k: offsets not ascending / out of range   */
+int rag_fault_flags(uint32_t* out_flags, int32_t clear);
+
 /* ---- dense exact kNN ----------------------------------------------------------
  * Replaces the embedded Qdrant store behind VectorIndexer.index_chunks
  * (reference src/indexing/vector_indexer.py:105-163: one fp32 vector per chunk,
@@ -140,20 +157,21 @@ int rag_merge_topk_f64_dev(const double* d_score, const int64_t* d_row, const in
  * src/indexing/hybrid_indexer.py:112-156) and _weighted_fusion (:158-218).
  * Per query: a vector list (rows [n_queries x vec_stride], vec_count[q] valid) and a
  * BM25 list.  canon: NULL, or canon[global row] = the first global row that carries the
- * same chunk_id (the reference fuses on the chunk_id string, which need not be unique).
+ * same chunk_id (the reference fuses on the chunk_id string, which need not be unique);
+ * n_canon = entries of that table (rows outside it fuse on their own id and are flagged).
  * Scores of both lists are fp64 (widen fp32 dense scores exactly before the call).
  * Outputs [n_queries x top_k]: out_pos = position of the payload-supplying entry in the
  * concatenation vector-list + BM25-list, out_row = its global row, out_score fp64.   */
 int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_count, int32_t vec_stride,
                      const int64_t* d_bm_row, const int32_t* d_bm_count, int32_t bm_stride,
-                     const uint32_t* d_canon, int32_t n_queries, int32_t top_k, double k_const,
-                     int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
+                     const uint32_t* d_canon, int64_t n_canon, int32_t n_queries, int32_t top_k,
+                     double k_const, int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
                      int32_t* d_out_count, void* stream);
 int rag_fuse_weighted_dev(const int64_t* d_vec_row, const double* d_vec_score,
                           const int32_t* d_vec_count, int32_t vec_stride,
                           const int64_t* d_bm_row, const double* d_bm_score,
                           const int32_t* d_bm_count, int32_t bm_stride,
-                          const uint32_t* d_canon, int32_t n_queries, int32_t top_k,
+                          const uint32_t* d_canon, int64_t n_canon, int32_t n_queries, int32_t top_k,
                           double vector_weight, double bm25_weight,
                           int32_t* d_out_pos, int64_t* d_out_row, double* d_out_score,
                           int32_t* d_out_count, void* stream);
@@ -173,10 +191,11 @@ int rag_fuse_weighted(const int64_t* vec_row, const double* vec_score, const int
 /* ---- rerank ---------------------------------------------------------------------
  * Replaces the stable descending sort + cut of BaseReranker.rerank (reference
  * src/reranker/rerank.py:42-43) for a batch of pools: scores of pool q are
- * d_score[seg_off[q] .. seg_off[q+1]); out_idx [n_queries x top_k] holds positions
- * inside the pool, best first, ties in pool order.                                 */
-int rag_topk_segmented_dev(const float* d_score, const int32_t* d_seg_off, int32_t n_queries,
-                           int32_t top_k, int32_t* d_out_idx, int32_t* d_out_count, void* stream);
+ * d_score[seg_off[q] .. seg_off[q+1]) of the n_scores given; out_idx [n_queries x top_k]
+ * holds positions inside the pool, best first, ties in pool order.                  */
+int rag_topk_segmented_dev(const float* d_score, int32_t n_scores, const int32_t* d_seg_off,
+                           int32_t n_queries, int32_t top_k, int32_t* d_out_idx,
+                           int32_t* d_out_count, void* stream);
 int rag_topk_segmented(const float* score, const int32_t* seg_off, int32_t n_queries,
                        int32_t top_k, int32_t* out_idx, int32_t* out_count);
 
@@ -186,17 +205,21 @@ int rag_topk_segmented(const float* score, const int32_t* seg_off, int32_t n_que
  * [CLS] query tokens [SEP] chunk tokens [SEP], the chunk part truncated so the pair
  * fits seq_len, written to row pair_slot[p] of the [n_slots x seq_len] outputs
  * (input ids, token type ids, attention mask), the rest padded with pad_id/0/0.
- * Token stores are CSR: tok[off[i] .. off[i+1]).  pair_row < 0 yields an all-pad row. */
-int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off,
-                    const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t chunk_row_base,
+ * Token stores are CSR: tok[off[i] .. off[i+1]) for n_queries queries and n_chunks chunks
+ * (chunk i is global row chunk_row_base + i).  pair_row < 0 yields an all-pad row; so does a
+ * pair whose query or row lies outside the stores (flagged).  pair_slot NULL = slot p.   */
+int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off, int32_t n_queries,
+                    const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t n_chunks,
+                    int64_t chunk_row_base,
                     const int32_t* d_pair_query, const int64_t* d_pair_row,
-                    const int32_t* d_pair_slot, int32_t n_pairs, int32_t seq_len,
+                    const int32_t* d_pair_slot, int32_t n_pairs, int32_t n_slots, int32_t seq_len,
                     int32_t cls_id, int32_t sep_id, int32_t pad_id,
                     int64_t* d_input_ids, int64_t* d_token_type_ids, int64_t* d_attention_mask,
                     void* stream);
 /* Length of each pair as rag_ce_pack_dev would write it (before padding, capped at
  * max_len); used to sort pairs into length buckets.                                */
-int rag_ce_pair_len_dev(const int64_t* d_query_off, const int64_t* d_chunk_off, int64_t chunk_row_base,
+int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int64_t* d_chunk_off,
+                        int64_t n_chunks, int64_t chunk_row_base,
                         const int32_t* d_pair_query, const int64_t* d_pair_row, int32_t n_pairs,
                         int32_t max_len, int32_t* d_out_len, void* stream);
 

@@ -82,6 +82,20 @@ def test_bm25_1m_properties():
         assert np.array_equal(row[i], order)
         assert np.array_equal(score[i], dense_scores[order])
     assert list(row[5]) == list(range(N - 1, N - 1 - k, -1)) and np.all(score[5] == 0)
+    # a batch large enough that several merge workgroups share a compute unit
+    big = []
+    for i in range(1024):
+        n = int(rng.integers(3, 13))
+        big.append(np.minimum(np.searchsorted(cdf, rng.random(n)), VOCAB - 1).astype(np.int32).tolist())
+    big[700] = [-1, -1]
+    score, row, cnt = idx.search(big, 100)
+    assert np.all(cnt == 100)
+    assert np.all((score[:, :-1] > score[:, 1:]) | ((score[:, :-1] == score[:, 1:]) & (row[:, :-1] > row[:, 1:])))
+    for i in (0, 255, 256, 300, 517, 700, 777, 1023):
+        dense_scores = idx.scores(big[i])
+        order = np.argsort(dense_scores, kind='stable')[::-1][:100]
+        assert np.array_equal(row[i], order), i
+        assert np.array_equal(score[i], dense_scores[order])
     ref = BM25OkapiArrays.from_token_ids(term, doc, ln, VOCAB)
     assert np.array_equal(ref.idf, arr.idf)
     for i in (0, 6, 40):
