@@ -277,6 +277,17 @@ def main():
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                 'traffic': None, 'avg_launch_ms': round(scan_s * 1e3, 3),
                 'algorithmic_gbs': round(4.0 * args.rows * args.dim / scan_s / 1e9, 1)}
+    # memory-side bytes of one launch from the PMC passes (FETCH_SIZE doubled as gfx950 needs,
+    # plus WRITE_SIZE), measured with scripts/kernel_bench.py on this workload and kept with
+    # the profiles; null when the workload differs from the one that was measured
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dense_scan.json')
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        w = pmc.get('workload', {})
+        if (w.get('rows'), w.get('dim'), w.get('batch'), w.get('k')) == (args.rows, args.dim, args.batch, 2 * t):
+            roofline['traffic'] = round(float(pmc['traffic_bytes_per_launch']) / 1e9, 2)
+            roofline['traffic_unit'] = 'GB per launch (rocprofv3 --pmc, separate passes)'
 
     result = {
         'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
@@ -310,6 +321,7 @@ def main():
         gpu_out = {'fused_row': o['fused_row'].cpu().numpy(), 'rows': o['rows'].cpu().numpy(),
                    'chunk_tokens': lambda rs: [tok_h[off_h[r]:off_h[r + 1]].tolist() for r in rs]}
         result['cpu_baseline'] = cpu_baseline(args, (bi_cpu, ce_cpu), rows, host, queries[0], gpu_out)
+    rag_hip.check_faults()          # every device-side consistency check held during the run
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
