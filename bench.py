@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--top-k', type=int, default=5)
     ap.add_argument('--rerank-top-n', type=int, default=50)
     ap.add_argument('--ce-dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--ce-torch-ops', action='store_true',
+                    help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
     ap.add_argument('--ce-arch', default='minilm-l6')
     ap.add_argument('--cpu-queries', type=int, default=4, help='queries timed on the host for cpu_baseline (0 = skip)')
@@ -222,7 +224,8 @@ def main():
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
     bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev)
     ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
-    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype)
+    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype,
+                               native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
                              rerank_top_n=args.rerank_top_n, dist=dist)

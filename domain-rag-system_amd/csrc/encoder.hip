@@ -1,0 +1,312 @@
+// Transformer-encoder kernels for the two BERT forwards of the path (bi-encoder behind
+// MedicalEmbedder.encode, reference src/indexing/embedder.py:65-71; cross-encoder behind
+// CrossEncoderReranker.score_pairs, reference src/reranker/rerank.py:79-84).  The GEMMs stay
+// with hipBLASLt; these kernels replace what sits between them.  gfx950 only.
+//
+//  attention_kernel   softmax(Q K^T / sqrt(D) + key mask) V for one (sequence, head) per
+//                     workgroup, straight from the packed [tokens][3][heads][D] projection
+//                     output to the [tokens][heads*D] layout the output projection reads
+//                     (no transposes, no score matrix in memory).  bf16 in/out, fp32 softmax,
+//                     v_mfma_f32_32x32x16_bf16 for both products.
+//  add_layernorm_kernel   LayerNorm(x + residual) in one pass, fp32 arithmetic, one wave per row.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_NT = 256;          // 4 waves; each takes 32-query blocks round-robin
+constexpr float NEG_BIG = -1e30f;    // finite stand-in for -inf (keeps max/exp free of NaN)
+
+// LDS image of one head's keys and values:
+//   K   [kpad][D + 8]     rows padded by 16 B: the 16-byte operand reads of 32 keys spread over the banks
+//   V^T [D][kpad + 4]     rows padded by 8 B: 32 lanes read 8 B of 32 different d rows without conflict
+template <int D>
+__global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restrict__ qkv,
+                                                           const int32_t* __restrict__ lens, int S, int NH,
+                                                           float scale, bf16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KROW = D + 8;
+    constexpr int DT = D / 32;                    // 32-row tiles of the transposed output
+    constexpr int KC = D / 16;                    // k-steps of the score product
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int seq = blockIdx.x / NH, head = blockIdx.x - seq * NH;
+    const int H = NH * D;
+    const size_t tok = (size_t)3 * H;             // elements per token of the projection output
+    const bf16* base = qkv + (size_t)seq * S * tok;
+    bf16* obase = out + (size_t)seq * S * H + head * D;
+    const int len = min(max(lens[seq], 0), S);
+    const int kpad = (len + 31) & ~31;
+    const int VROW = kpad + 4;
+    bf16* Ks = reinterpret_cast<bf16*>(smem);
+    bf16* Vt = Ks + (size_t)kpad * KROW;
+
+    // ---- stage this head's keys (row-major) and values (transposed), zero beyond len
+    for (int idx = tid; idx < kpad * (D / 8); idx += ATT_NT) {
+        const int key = idx / (D / 8), c8 = idx - key * (D / 8);
+        bf16x8 kv, vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+        if (key < len) {
+            const bf16* p = base + (size_t)key * tok + head * D + c8 * 8;
+            kv = *reinterpret_cast<const bf16x8*>(p + H);
+            vv = *reinterpret_cast<const bf16x8*>(p + 2 * H);
+        }
+        *reinterpret_cast<bf16x8*>(Ks + key * KROW + c8 * 8) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c8 * 8 + j) * VROW + key] = vv[j];
+    }
+    __syncthreads();
+
+    for (int qb = wave; qb * 32 < S; qb += ATT_NT / 64) {
+        const int q = qb * 32 + r;
+        if (qb * 32 >= len) {
+            // padding rows only: defined (zero) output, nothing to compute
+            for (int i = lane; i < 32 * (D / 8); i += 64) {
+                const int row = qb * 32 + i / (D / 8), c8 = i % (D / 8);
+                if (row < S) {
+                    bf16x8 z;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+                    *reinterpret_cast<bf16x8*>(obase + (size_t)row * H + c8 * 8) = z;
+                }
+            }
+            continue;
+        }
+        // Q^T fragments (B operand): lane (h, r) holds Q[q][16c + 8h + j]
+        bf16x8 qf[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
+            if (q < S) qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * tok + head * D + 16 * c + 8 * h);
+        }
+        float m_run = NEG_BIG, l_run = 0.f;
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+
+        for (int kb = 0; kb < kpad; kb += 32) {
+            // S^T tile: rows = keys kb..kb+31 (registers + lane half), column = this lane's query
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kb + r) * KROW + 16 * c + 8 * h);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[c], s, 0, 0, 0);
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                s[i] = key < len ? s[i] * scale : NEG_BIG;
+                mx = fmaxf(mx, s[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float p = key < len ? __expf(s[i] - m_new) : 0.f;
+                s[i] = p;
+                sum += p;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            // O^T += V^T P^T: the score registers 8t..8t+7 are the B fragment of k-step t; element j of
+            // lane half h is key kb + 16t + 8(j>>2) + 4h + (j&3), so V^T is read in that order
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (bf16)s[8 * t + j];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16* vp = Vt + (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vp + 8);
+                    bf16x8 av;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { av[j] = lo[j]; av[4 + j] = hi[j]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        // O^T tile: rows = d (registers + lane half), column = this lane's query
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        if (q < S) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[dt][4 * g + j] * inv);
+                    *reinterpret_cast<bf16x4*>(obase + (size_t)q * H + dt * 32 + 8 * g + 4 * h) = v;
+                }
+        }
+    }
+}
+
+// ---- LayerNorm(x + residual) ---------------------------------------------------------------
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    typedef bf16x8 type;
+    __device__ static void load(const bf16* p, float* f) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    __device__ static void store(bf16* p, const float* f) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+template <> struct Vec8<float> {
+    __device__ static void load(const float* p, float* f) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    __device__ static void store(float* p, const float* f) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+
+constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes up to 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                            float eps, int64_t rows, int H, T* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n_chunks = H / 8;
+    float v[LN_MAX_CHUNKS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            Vec8<T>::load(x + row * H + ch * 8, v[c]);
+            if (res != nullptr) {
+                float rr[8];
+                Vec8<T>::load(res + row * H + ch * 8, rr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] += rr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[c][j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float g[8], b[8], y[8];
+            Vec8<T>::load(gamma + ch * 8, g);
+            Vec8<T>::load(beta + ch * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+            Vec8<T>::store(out + row * H + ch * 8, y);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
+                                     int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(n_seq >= 0 && seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention: bad sizes");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attention: only bf16 is implemented");
+    RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention: head_dim must be 32 or 64 (got %d)",
+                head_dim);
+    RAG_REQUIRE(seq_len <= RAG_ENC_MAX_SEQ, RAG_ELIMIT, "rag_enc_attention: seq_len %d exceeds %d", seq_len,
+                RAG_ENC_MAX_SEQ);
+    if (n_seq == 0) return RAG_OK;
+    RAG_REQUIRE(d_qkv && d_lens && d_out, RAG_EINVAL, "rag_enc_attention: null pointer");
+    RAG_REQUIRE((int64_t)n_seq * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention: too many (sequence, head) pairs");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int kpad = (seq_len + 31) & ~31;
+    const size_t lds = (size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2;
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const unsigned grid = (unsigned)((int64_t)n_seq * n_heads);
+    if (head_dim == 32) {
+        static size_t granted = 64 * 1024;
+        if (lds > granted) {
+            RAG_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024));
+            granted = 160 * 1024;
+        }
+        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, seq_len, n_heads, scale,
+                                                            (bf16*)d_out);
+    } else {
+        static size_t granted = 64 * 1024;
+        if (lds > granted) {
+            RAG_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024));
+            granted = 160 * 1024;
+        }
+        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, seq_len, n_heads, scale,
+                                                            (bf16*)d_out);
+    }
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual, const void* d_gamma,
+                                         const void* d_beta, float eps, int64_t rows, int32_t hidden, int32_t dtype,
+                                         void* d_out, void* stream_) {
+    RAG_REQUIRE(rows >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
+                "rag_enc_add_layernorm: hidden must be a multiple of 8 up to %d (got %d)", 8 * 64 * LN_MAX_CHUNKS, hidden);
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_add_layernorm: unknown dtype");
+    if (rows == 0) return RAG_OK;
+    RAG_REQUIRE(d_x && d_gamma && d_beta && d_out, RAG_EINVAL, "rag_enc_add_layernorm: null pointer");
+    RAG_REQUIRE((rows + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_add_layernorm: too many rows");
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == RAG_DTYPE_BF16)
+        add_layernorm_kernel<bf16><<<grid, 256, 0, stream>>>((const bf16*)d_x, (const bf16*)d_residual,
+                                                             (const bf16*)d_gamma, (const bf16*)d_beta, eps, rows, hidden,
+                                                             (bf16*)d_out);
+    else
+        add_layernorm_kernel<float><<<grid, 256, 0, stream>>>((const float*)d_x, (const float*)d_residual,
+                                                              (const float*)d_gamma, (const float*)d_beta, eps, rows,
+                                                              hidden, (float*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}

@@ -71,8 +71,19 @@ class BertLayer(nn.Module):
         self.ffn_out = nn.Linear(c.intermediate_size, c.hidden_size)
         self.ffn_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
 
-    def forward(self, x, attn_bias):
+    def forward(self, x, attn_bias, lens=None):
+        """`lens` (int32 [B], real tokens per sequence) selects the librag_hip kernels for what
+        sits between the GEMMs: fused attention straight from the packed projection, and
+        residual + LayerNorm in one pass.  Without it (CPU, or a shape the kernels do not
+        cover) the same arithmetic runs as PyTorch ops."""
         b, s, h = x.shape
+        if lens is not None:
+            import rag_hip
+            ctx = rag_hip.enc_attention_dev(self.qkv(x), lens, self.heads)
+            x = rag_hip.enc_add_layernorm_dev(self.attn_out(ctx), x, self.attn_norm.weight, self.attn_norm.bias,
+                                              self.attn_norm.eps)
+            return rag_hip.enc_add_layernorm_dev(self.ffn_out(F.gelu(self.ffn_in(x))), x, self.ffn_norm.weight,
+                                                 self.ffn_norm.bias, self.ffn_norm.eps)
         qkv = self.qkv(x).view(b, s, 3, self.heads, h // self.heads).permute(2, 0, 3, 1, 4)
         ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=attn_bias)
         ctx = ctx.transpose(1, 2).reshape(b, s, h)
@@ -89,6 +100,7 @@ class BertEncoder(nn.Module):
         self.token_type = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.emb_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
         self.layers = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
+        self.native = False          # set by load_model(native=True): use the librag_hip encoder kernels
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         b, s = input_ids.shape
@@ -96,6 +108,19 @@ class BertEncoder(nn.Module):
         x = self.word(input_ids) + self.position(pos)[None, :, :]
         x = x + self.token_type(token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids))
         x = self.emb_norm(x)
+        c = self.config
+        if self.native and x.is_cuda:
+            import rag_hip
+            if not rag_hip.enc_attention_supported(x.dtype, c.hidden_size // c.num_attention_heads, s):
+                raise ValueError(f"the librag_hip encoder kernels do not cover dtype {x.dtype}, head size "
+                                 f"{c.hidden_size // c.num_attention_heads}, sequence length {s}")
+            # BERT masks by position validity; tokenised batches are left-aligned, so a length per
+            # sequence carries the same information as the mask
+            lens = (attention_mask.sum(dim=1) if attention_mask is not None
+                    else torch.full((b,), s, device=x.device)).to(torch.int32)
+            for layer in self.layers:
+                x = layer(x, None, lens)
+            return x
         bias = None
         if attention_mask is not None:
             bias = torch.zeros((b, 1, 1, s), dtype=x.dtype, device=x.device)
@@ -234,8 +259,10 @@ def _resolve_dir(spec):
             f"({type(e).__name__}); pass a directory or a 'random:<arch>' spec") from e
 
 
-def load_model(spec, kind, device, dtype=torch.float32, seed=0):
-    """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config)."""
+def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False):
+    """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config).
+    native=True runs attention and residual+LayerNorm through the librag_hip kernels (GPU,
+    bfloat16, left-aligned attention masks); shapes they do not cover raise."""
     cls = BiEncoder if kind == 'bi' else CrossEncoderModel
     if spec.startswith('random:'):
         arch = spec.split(':', 1)[1]
@@ -264,6 +291,7 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0):
             raise RuntimeError(f"checkpoint under {directory} lacks weights: {bad[:5]}")
         tok = FileTokenizer(directory)
     model.eval().to(device=device, dtype=dtype)
+    model.bert.native = bool(native)
     return model, tok, cfg
 
 

@@ -16,6 +16,8 @@ METRIC_COSINE, METRIC_DOT, METRIC_EUCLID = 0, 1, 2
 MEM_HOST_COPY, MEM_DEVICE_COPY, MEM_DEVICE_BORROW = 0, 1, 2
 MAX_K = 1024
 MAX_FUSE_LIST = 512
+DTYPE_F32, DTYPE_BF16 = 0, 1
+ENC_MAX_SEQ = 512
 
 _METRICS = {'cosine': METRIC_COSINE, 'dot': METRIC_DOT, 'euclidean': METRIC_EUCLID, 'euclid': METRIC_EUCLID}
 
@@ -61,6 +63,8 @@ SIGNATURES = {
     'rag_ce_pack_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                _i32, _vp, _vp, _vp, _vp]),
     'rag_ce_pair_len_dev': (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_dev': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None
@@ -536,3 +540,42 @@ def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair
                                 _ptr(pair_slot, torch.int32), n, int(n_slots), int(seq_len), int(cls_id), int(sep_id),
                                 int(pad_id), _ptr(ids), _ptr(types), _ptr(mask), _stream()), 'rag_ce_pack_dev')
     return ids, types, mask
+
+
+# ---- transformer encoder pieces ----------------------------------------------------------------
+def enc_attention_supported(dtype, head_dim, seq_len):
+    import torch
+    return dtype == torch.bfloat16 and head_dim in (32, 64) and seq_len <= ENC_MAX_SEQ
+
+
+def enc_attention_dev(qkv, lens, n_heads):
+    """qkv [B, S, 3*H] bf16 (query | key | value, heads inside each), lens [B] int32 ->
+    context [B, S, H] bf16 (rag_enc_attention_dev)."""
+    import torch
+    b, s, h3 = qkv.shape
+    hidden = h3 // 3
+    out = torch.empty((b, s, hidden), dtype=qkv.dtype, device=qkv.device)
+    if tuple(lens.shape) != (b,):
+        raise ValueError("lens must hold one length per sequence")
+    check(lib().rag_enc_attention_dev(_ptr(qkv, torch.bfloat16), _ptr(lens, torch.int32), b, s, int(n_heads),
+                                      hidden // int(n_heads), DTYPE_BF16, _ptr(out), _stream()),
+          'rag_enc_attention_dev')
+    return out
+
+
+def enc_add_layernorm_dev(x, residual, gamma, beta, eps):
+    """LayerNorm(x + residual) over the last dimension, one kernel (rag_enc_add_layernorm_dev)."""
+    import torch
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("enc_add_layernorm_dev handles bfloat16 and float32")
+    hidden = x.shape[-1]
+    rows = x.numel() // hidden
+    if residual is not None and residual.shape != x.shape:
+        raise ValueError("residual must have the shape of x")
+    if tuple(gamma.shape) != (hidden,) or tuple(beta.shape) != (hidden,):
+        raise ValueError("gamma and beta must have one entry per hidden unit")
+    out = torch.empty_like(x)
+    check(lib().rag_enc_add_layernorm_dev(_ptr(x), _ptr(residual, x.dtype), _ptr(gamma, x.dtype), _ptr(beta, x.dtype),
+                                          float(eps), rows, hidden, DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32,
+                                          _ptr(out), _stream()), 'rag_enc_add_layernorm_dev')
+    return out

@@ -223,6 +223,30 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
                         const int32_t* d_pair_query, const int64_t* d_pair_row, int32_t n_pairs,
                         int32_t max_len, int32_t* d_out_len, void* stream);
 
+/* ---- transformer encoder pieces ---------------------------------------------------
+ * The two BERT forwards of the path (SentenceTransformer.encode behind
+ * MedicalEmbedder.encode, reference src/indexing/embedder.py:65-71; CrossEncoder.predict
+ * behind CrossEncoderReranker.score_pairs, reference src/reranker/rerank.py:79-84) keep
+ * their GEMMs in hipBLASLt; these entry points are what runs between the GEMMs.        */
+#define RAG_DTYPE_F32   0
+#define RAG_DTYPE_BF16  1
+#define RAG_ENC_MAX_SEQ 512   /* longest sequence of rag_enc_attention_dev              */
+
+/* Self-attention of n_seq padded sequences: qkv is the packed projection output
+ * [n_seq][seq_len][3][n_heads][head_dim] (query, key, value), lens[i] = real tokens of
+ * sequence i (keys at or beyond it are masked, as BERT's additive attention mask does);
+ * out [n_seq][seq_len][n_heads*head_dim] = softmax(Q K^T / sqrt(head_dim)) V per head.
+ * Rows of padding positions are written (finite), rows of 32-row blocks that hold only
+ * padding are zero.  bf16 only; head_dim 32 or 64.                                      */
+int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
+                          int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* out[r] = LayerNorm(x[r] + residual[r]) * gamma + beta over `hidden` elements per row
+ * (residual may be NULL); fp32 arithmetic, inputs/outputs bf16 or fp32 as `dtype` says;
+ * hidden a multiple of 8 up to 2048.  out may alias x or residual.                     */
+int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual, const void* d_gamma,
+                              const void* d_beta, float eps, int64_t rows, int32_t hidden,
+                              int32_t dtype, void* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

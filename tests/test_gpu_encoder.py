@@ -1,0 +1,102 @@
+"""GPU: the encoder kernels between the GEMMs (fused attention, residual + LayerNorm) against
+plain PyTorch fp32 references of the same operations."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_attention(qkv, lens, heads):
+    b, s, h3 = qkv.shape
+    h = h3 // 3
+    q, k, v = qkv.float().view(b, s, 3, heads, h // heads).permute(2, 0, 3, 1, 4)
+    bias = torch.zeros((b, 1, 1, s), device=qkv.device)
+    bias.masked_fill_(torch.arange(s, device=qkv.device)[None, None, None, :] >= lens[:, None, None, None], -1e30)
+    p = torch.softmax(q @ k.transpose(-1, -2) / (h // heads) ** 0.5 + bias, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(b, s, h)
+
+
+@pytest.mark.parametrize('b,s,heads,d', [(7, 48, 12, 32), (5, 160, 12, 32), (3, 33, 4, 64), (2, 512, 2, 32),
+                                         (2, 300, 3, 64), (9, 8, 12, 32)])
+def test_attention_matches_fp32_reference(b, s, heads, d):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(b * 1000 + s)
+    qkv = (torch.randn((b, s, 3 * heads * d), generator=g, device=dev) * 1.5).to(torch.bfloat16)
+    lens = torch.randint(1, s + 1, (b,), generator=g, device=dev, dtype=torch.int32)
+    lens[0] = s
+    if b > 2:
+        lens[1] = 1
+        lens[2] = 0                                   # an empty slot: defined (zero) output
+    out = rag_hip.enc_attention_dev(qkv, lens, heads).float()
+    ref = _ref_attention(qkv, lens, heads)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    for i in range(b):
+        n = int(lens[i])
+        if n == 0:
+            assert float(out[i].abs().max()) == 0.0
+            continue
+        # real tokens: bf16 output of an fp32 softmax over bf16 products
+        err = (out[i, :n] - ref[i, :n]).abs().max()
+        assert float(err) < 2e-2, (i, n, float(err))
+        # padding rows of a block that holds real tokens attend over the real keys too
+        blk_end = min(s, (n + 31) // 32 * 32)
+        assert float((out[i, n:blk_end] - ref[i, n:blk_end]).abs().max() if blk_end > n else 0.0) < 2e-2
+        assert float(out[i, blk_end:].abs().max() if blk_end < s else 0.0) == 0.0
+
+
+def test_attention_argument_errors():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    qkv = torch.zeros((1, 8, 3 * 48), dtype=torch.bfloat16, device=dev)
+    lens = torch.ones(1, dtype=torch.int32, device=dev)
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_attention_dev(qkv, lens, 3)          # head size 16
+    with pytest.raises(ValueError):
+        rag_hip.enc_attention_dev(qkv.float(), lens, 1)
+    big = torch.zeros((1, 513, 3 * 32), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_attention_dev(big, lens, 1)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize('rows,hidden', [(1000, 384), (37, 768), (5, 2048), (3, 8)])
+def test_add_layernorm_matches_reference(dtype, tol, rows, hidden):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(rows + hidden)
+    x = (torch.randn((rows, hidden), generator=g, device=dev) * 2 + 0.5).to(dtype)
+    res = torch.randn((rows, hidden), generator=g, device=dev).to(dtype)
+    gamma = (1 + 0.1 * torch.randn((hidden,), generator=g, device=dev)).to(dtype)
+    beta = (0.1 * torch.randn((hidden,), generator=g, device=dev)).to(dtype)
+    for r in (res, None):
+        out = rag_hip.enc_add_layernorm_dev(x, r, gamma, beta, 1e-12).float()
+        v = x.double() + (r.double() if r is not None else 0)
+        ref = torch.nn.functional.layer_norm(v, (hidden,), gamma.double(), beta.double(), 1e-12)
+        assert float((out - ref).abs().max()) < tol
+
+
+def test_cross_encoder_with_native_kernels_tracks_fp32():
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    ref, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32)
+    plain, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.bfloat16)
+    native, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.bfloat16, native=True)
+    g = torch.Generator(device=dev).manual_seed(3)
+    b, s = 64, 96
+    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev)
+    lens = torch.randint(5, s + 1, (b,), generator=g, device=dev)
+    mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
+    types = (torch.arange(s, device=dev)[None, :] >= (lens[:, None] // 3)).long() * mask
+    with torch.no_grad():
+        a = ref(ids, types, mask)
+        p = plain(ids, types, mask)
+        n = native(ids, types, mask)
+    torch.cuda.synchronize()
+    err_plain = float((p - a).abs().max())
+    err_native = float((n - a).abs().max())
+    spread = float(a.std())
+    # the kernels keep more of the arithmetic in fp32 than the PyTorch bf16 ops do
+    assert err_native <= max(1.5 * err_plain, 0.02 * spread + 1e-3), (err_native, err_plain, spread)
