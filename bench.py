@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--top-k', type=int, default=5)
     ap.add_argument('--rerank-top-n', type=int, default=50)
     ap.add_argument('--ce-dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--ce-pairs-per-batch', type=int, default=16384,
+                    help='pairs per cross-encoder forward (an unpadded token stream when the model runs the librag_hip kernels)')
     ap.add_argument('--ce-torch-ops', action='store_true',
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
@@ -228,7 +230,7 @@ def main():
                                native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
-                             rerank_top_n=args.rerank_top_n, dist=dist)
+                             rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
 

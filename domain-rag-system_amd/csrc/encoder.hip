@@ -28,8 +28,10 @@ constexpr float NEG_BIG = -1e30f;    // finite stand-in for -inf (keeps max/exp 
 //   V^T [D][kpad + 4]     rows padded by 8 B: 32 lanes read 8 B of 32 different d rows without conflict
 template <int D>
 __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restrict__ qkv,
-                                                           const int32_t* __restrict__ lens, int S, int NH,
-                                                           float scale, bf16* __restrict__ out) {
+                                                           const int32_t* __restrict__ lens,
+                                                           const int32_t* __restrict__ cu, int64_t total_tokens,
+                                                           int S_max, int NH, float scale, bf16* __restrict__ out,
+                                                           uint32_t* fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KROW = D + 8;
     constexpr int DT = D / 32;                    // 32-row tiles of the transposed output
@@ -39,9 +41,26 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
     const int seq = blockIdx.x / NH, head = blockIdx.x - seq * NH;
     const int H = NH * D;
     const size_t tok = (size_t)3 * H;             // elements per token of the projection output
-    const bf16* base = qkv + (size_t)seq * S * tok;
-    bf16* obase = out + (size_t)seq * S * H + head * D;
-    const int len = min(max(lens[seq], 0), S);
+    // padded batch: sequence i owns rows [i*S_max, (i+1)*S_max), lens[i] of them real;
+    // packed batch: sequence i owns rows [cu[i], cu[i+1]), all real
+    int64_t first;
+    int S, len;
+    if (cu != nullptr) {
+        first = cu[seq];
+        const int64_t n = (int64_t)cu[seq + 1] - first;
+        if (first < 0 || n < 0 || n > S_max || first + n > total_tokens) {   // not a sequence of this batch
+            if (threadIdx.x == 0) rag_flag(fault, RAG_FAULT_SEGMENT);
+            return;
+        }
+        len = (int)n;
+        S = len;
+    } else {
+        first = (int64_t)seq * S_max;
+        S = S_max;
+        len = min(max(lens[seq], 0), S);
+    }
+    const bf16* base = qkv + (size_t)first * tok;
+    bf16* obase = out + (size_t)first * H + head * D;
     const int kpad = (len + 31) & ~31;
     const int VROW = kpad + 4;
     bf16* Ks = reinterpret_cast<bf16*>(smem);
@@ -247,10 +266,95 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict_
     }
 }
 
+// LayerNorm(word[id] + position[pos] + type[tt]) per token, one wave per token.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __restrict__ ids,
+                                                              const int32_t* __restrict__ types,
+                                                              const int32_t* __restrict__ pos, const T* __restrict__ word,
+                                                              const T* __restrict__ position, const T* __restrict__ type_emb,
+                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                              float eps, int64_t n_tokens, int H, int vocab, int max_pos,
+                                                              int n_types, T* __restrict__ out, uint32_t* fault) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tokens) return;
+    int id = ids[t], ps = pos[t], tt = types != nullptr ? types[t] : 0;
+    if (id < 0 || id >= vocab || ps < 0 || ps >= max_pos || tt < 0 || tt >= n_types) {
+        if (lane == 0) rag_flag(fault, RAG_FAULT_TOKEN);     // outside the tables: embed as entry 0
+        id = min(max(id, 0), vocab - 1);
+        ps = min(max(ps, 0), max_pos - 1);
+        tt = min(max(tt, 0), n_types - 1);
+    }
+    const int n_chunks = H / 8;
+    float v[LN_MAX_CHUNKS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float a[8], b[8];
+            Vec8<T>::load(word + (size_t)id * H + ch * 8, v[c]);
+            Vec8<T>::load(position + (size_t)ps * H + ch * 8, a);
+            Vec8<T>::load(type_emb + (size_t)tt * H + ch * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] += a[j] + b[j]; sum += v[c][j]; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float g[8], b[8], y[8];
+            Vec8<T>::load(gamma + ch * 8, g);
+            Vec8<T>::load(beta + ch * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+            Vec8<T>::store(out + t * H + ch * 8, y);
+        }
+    }
+}
+
 }  // namespace
+
+namespace {
+int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
+                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_);
+}
 
 extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
                                      int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(d_lens != nullptr || n_seq == 0, RAG_EINVAL, "rag_enc_attention: null lengths");
+    return attention_launch(d_qkv, d_lens, nullptr, (int64_t)n_seq * seq_len, n_seq, seq_len, n_heads, head_dim, dtype,
+                            d_out, stream_);
+}
+
+extern "C" int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
+                                            int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                            int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(d_cu_seqlens != nullptr || n_seq == 0, RAG_EINVAL, "rag_enc_attention_packed: null offsets");
+    RAG_REQUIRE(total_tokens >= 0 && total_tokens < (1ll << 31), RAG_ELIMIT, "rag_enc_attention_packed: bad token count");
+    return attention_launch(d_qkv, nullptr, d_cu_seqlens, total_tokens, n_seq, max_seq_len, n_heads, head_dim, dtype,
+                            d_out, stream_);
+}
+
+namespace {
+int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
+                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
     RAG_REQUIRE(n_seq >= 0 && seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention: bad sizes");
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attention: only bf16 is implemented");
     RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention: head_dim must be 32 or 64 (got %d)",
@@ -258,7 +362,7 @@ extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, i
     RAG_REQUIRE(seq_len <= RAG_ENC_MAX_SEQ, RAG_ELIMIT, "rag_enc_attention: seq_len %d exceeds %d", seq_len,
                 RAG_ENC_MAX_SEQ);
     if (n_seq == 0) return RAG_OK;
-    RAG_REQUIRE(d_qkv && d_lens && d_out, RAG_EINVAL, "rag_enc_attention: null pointer");
+    RAG_REQUIRE(d_qkv && d_out, RAG_EINVAL, "rag_enc_attention: null pointer");
     RAG_REQUIRE((int64_t)n_seq * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention: too many (sequence, head) pairs");
     hipStream_t stream = (hipStream_t)stream_;
     const int kpad = (seq_len + 31) & ~31;
@@ -272,8 +376,8 @@ extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, i
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, seq_len, n_heads, scale,
-                                                            (bf16*)d_out);
+        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, seq_len, n_heads,
+                                                            scale, (bf16*)d_out, rag_fault_word());
     } else {
         static size_t granted = 64 * 1024;
         if (lds > granted) {
@@ -281,12 +385,13 @@ extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, i
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, seq_len, n_heads, scale,
-                                                            (bf16*)d_out);
+        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, seq_len, n_heads,
+                                                            scale, (bf16*)d_out, rag_fault_word());
     }
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
+}  // namespace
 
 extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual, const void* d_gamma,
                                          const void* d_beta, float eps, int64_t rows, int32_t hidden, int32_t dtype,
@@ -307,6 +412,37 @@ extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual
         add_layernorm_kernel<float><<<grid, 256, 0, stream>>>((const float*)d_x, (const float*)d_residual,
                                                               (const float*)d_gamma, (const float*)d_beta, eps, rows,
                                                               hidden, (float*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
+                                           const void* d_word, const void* d_position, const void* d_type_emb,
+                                           const void* d_gamma, const void* d_beta, float eps, int64_t n_tokens,
+                                           int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
+                                           int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(n_tokens >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
+                "rag_enc_embed_layernorm: hidden must be a multiple of 8 up to %d (got %d)", 8 * 64 * LN_MAX_CHUNKS, hidden);
+    RAG_REQUIRE(vocab >= 1 && max_pos >= 1 && n_types >= 1, RAG_EINVAL, "rag_enc_embed_layernorm: empty table");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_embed_layernorm: unknown dtype");
+    if (n_tokens == 0) return RAG_OK;
+    RAG_REQUIRE(d_ids && d_pos && d_word && d_position && d_type_emb && d_gamma && d_beta && d_out, RAG_EINVAL,
+                "rag_enc_embed_layernorm: null pointer");
+    RAG_REQUIRE((n_tokens + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_embed_layernorm: too many tokens");
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned grid = (unsigned)((n_tokens + 3) / 4);
+    if (dtype == RAG_DTYPE_BF16)
+        embed_layernorm_kernel<bf16><<<grid, 256, 0, stream>>>(d_ids, d_types, d_pos, (const bf16*)d_word,
+                                                               (const bf16*)d_position, (const bf16*)d_type_emb,
+                                                               (const bf16*)d_gamma, (const bf16*)d_beta, eps, n_tokens,
+                                                               hidden, vocab, max_pos, n_types, (bf16*)d_out,
+                                                               rag_fault_word());
+    else
+        embed_layernorm_kernel<float><<<grid, 256, 0, stream>>>(d_ids, d_types, d_pos, (const float*)d_word,
+                                                                (const float*)d_position, (const float*)d_type_emb,
+                                                                (const float*)d_gamma, (const float*)d_beta, eps,
+                                                                n_tokens, hidden, vocab, max_pos, n_types,
+                                                                (float*)d_out, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

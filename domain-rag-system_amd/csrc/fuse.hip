@@ -235,6 +235,58 @@ __global__ __launch_bounds__(256) void ce_pack_kernel(const int32_t* __restrict_
     }
 }
 
+// One wave per pair, packed (unpadded) output.
+__global__ __launch_bounds__(256) void ce_pack_packed_kernel(const int32_t* __restrict__ query_tok,
+                                                             const int64_t* __restrict__ query_off, int n_queries,
+                                                             const int32_t* __restrict__ chunk_tok,
+                                                             const int64_t* __restrict__ chunk_off, int64_t n_chunks,
+                                                             int64_t chunk_row_base,
+                                                             const int32_t* __restrict__ pair_query,
+                                                             const int64_t* __restrict__ pair_row,
+                                                             const int32_t* __restrict__ cu, int n_pairs,
+                                                             int64_t total_tokens, int max_len, int cls_id, int sep_id,
+                                                             int32_t* __restrict__ ids, int32_t* __restrict__ types,
+                                                             int32_t* __restrict__ pos, uint32_t* fault) {
+    const int lane = threadIdx.x & 63;
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pr >= n_pairs) return;
+    const int64_t start = cu[pr];
+    const int64_t n = (int64_t)cu[pr + 1] - start;
+    if (n == 0) return;
+    const int64_t row = pair_row[pr];
+    const int64_t lrow = row - chunk_row_base;
+    const int qi = pair_query[pr];
+    bool bad = start < 0 || n < 0 || start + n > total_tokens || row < 0 || lrow < 0 || lrow >= n_chunks || qi < 0 ||
+               qi >= n_queries;
+    int qn = 0, cn = 0;
+    int64_t qb = 0, cb = 0;
+    if (!bad) {
+        qb = query_off[qi];
+        cb = chunk_off[lrow];
+        qn = max((int)(query_off[qi + 1] - qb), 0);
+        cn = max((int)(chunk_off[lrow + 1] - cb), 0);
+        qn = min(qn, max(max_len - 3, 0));
+        cn = min(cn, max(max_len - 3 - qn, 0));
+        bad = qn + cn + 3 != n;                          // cu was not built from these lengths
+    }
+    if (bad) {
+        if (lane == 0) rag_flag(fault, RAG_FAULT_CE_PAIR);
+        return;
+    }
+    const int first = 2 + qn;                            // [CLS] q.. [SEP]
+    for (int i = lane; i < (int)n; i += 64) {
+        int tok, tt = 0;
+        if (i == 0) tok = cls_id;
+        else if (i < 1 + qn) tok = query_tok[qb + i - 1];
+        else if (i == 1 + qn) tok = sep_id;
+        else if (i < first + cn) { tok = chunk_tok[cb + i - first]; tt = 1; }
+        else { tok = sep_id; tt = 1; }
+        ids[start + i] = tok;
+        types[start + i] = tt;
+        pos[start + i] = i;
+    }
+}
+
 __global__ void ce_pair_len_kernel(const int64_t* __restrict__ query_off, int n_queries,
                                    const int64_t* __restrict__ chunk_off, int64_t n_chunks,
                                    int64_t chunk_row_base, const int32_t* __restrict__ pair_query,
@@ -457,6 +509,26 @@ extern "C" int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_quer
         d_query_tok, d_query_off, n_queries, d_chunk_tok, d_chunk_off, n_chunks, chunk_row_base, d_pair_query,
         d_pair_row, d_pair_slot, n_pairs, n_slots, seq_len, cls_id, sep_id, pad_id, d_input_ids, d_token_type_ids,
         d_attention_mask, rag_fault_word());
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_ce_pack_packed_dev(const int32_t* d_query_tok, const int64_t* d_query_off, int32_t n_queries,
+                                      const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t n_chunks,
+                                      int64_t chunk_row_base, const int32_t* d_pair_query, const int64_t* d_pair_row,
+                                      const int32_t* d_cu, int32_t n_pairs, int64_t total_tokens, int32_t max_len,
+                                      int32_t cls_id, int32_t sep_id, int32_t* d_input_ids, int32_t* d_token_type_ids,
+                                      int32_t* d_positions, void* stream) {
+    RAG_REQUIRE(n_pairs >= 0 && max_len >= 3 && total_tokens >= 0 && n_queries >= 0 && n_chunks >= 0, RAG_EINVAL,
+                "rag_ce_pack_packed: bad sizes");
+    if (n_pairs == 0 || total_tokens == 0) return RAG_OK;
+    RAG_REQUIRE(d_query_tok && d_query_off && d_chunk_tok && d_chunk_off && d_pair_query && d_pair_row && d_cu &&
+                    d_input_ids && d_token_type_ids && d_positions,
+                RAG_EINVAL, "rag_ce_pack_packed: null pointer");
+    ce_pack_packed_kernel<<<(n_pairs + 3) / 4, 256, 0, (hipStream_t)stream>>>(
+        d_query_tok, d_query_off, n_queries, d_chunk_tok, d_chunk_off, n_chunks, chunk_row_base, d_pair_query,
+        d_pair_row, d_cu, n_pairs, total_tokens, max_len, cls_id, sep_id, d_input_ids, d_token_type_ids, d_positions,
+        rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

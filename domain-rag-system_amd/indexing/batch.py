@@ -48,12 +48,17 @@ class BatchSearcher:
                  canon: Optional[torch.Tensor] = None, bi_encoder=None, cross_encoder=None,
                  chunk_tokens: Optional[TokenStore] = None, top_k: int = 5, rerank_top_n: int = 50,
                  fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
-                 ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None):
+                 ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None,
+                 ce_packed=None):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
         self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
         self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
+        # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
+        self.ce_packed = bool(ce_packed) if ce_packed is not None else (
+            cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
+            and next(cross_encoder.parameters()).dtype == torch.bfloat16)
         self.cls_id, self.sep_id, self.pad_id = special_ids
         self.dist = dist                                  # torch.distributed module when sharded
         self.world = dist.get_world_size() if dist is not None else 1
@@ -133,22 +138,10 @@ class BatchSearcher:
         logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
-            order = torch.argsort(plen, descending=True)
-            sorted_len = plen[order]
-            # longest pair of every mini-batch (one small copy to the host sizes the buffers)
-            starts = list(range(0, n_mine, self.ce_pairs_per_batch))
-            heads = sorted_len[torch.tensor(starts, device=dev)].cpu().tolist()
-            for s0, longest in zip(starts, heads):
-                s1 = min(s0 + self.ce_pairs_per_batch, n_mine)
-                if longest <= 0:
-                    continue                               # only empty slots (row -1) left
-                seq = max(8, (int(longest) + 7) // 8 * 8)
-                idx = order[s0:s1]
-                ids, types, mask = rag_hip.ce_pack_dev(
-                    q_tok, q_off, store.tok, store.off, store.row_base, my_q[idx].contiguous(),
-                    my_r[idx].contiguous(), None, s1 - s0, seq, self.cls_id, self.sep_id, self.pad_id)
-                out = self.cross_encoder(ids, types, mask)
-                logits_mine[idx] = out.float()
+            if self.ce_packed:
+                self._ce_packed(q_tok, q_off, my_q, my_r, plen, logits_mine)
+            else:
+                self._ce_padded(q_tok, q_off, my_q, my_r, plen, logits_mine)
         if self.world > 1:
             gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
             self.dist.all_gather_into_tensor(gathered, logits_mine)
@@ -166,6 +159,58 @@ class BatchSearcher:
             flat = logits[keep].contiguous()
         idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
         return idx, cnt, logits
+
+    def _ce_padded(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+        """Pairs sorted by length, padded mini-batches (any model dtype, PyTorch or native ops)."""
+        store = self.chunk_tokens
+        n_mine = my_r.shape[0]
+        dev = my_r.device
+        order = torch.argsort(plen, descending=True)
+        sorted_len = plen[order]
+        # longest pair of every mini-batch (one small copy to the host sizes the buffers)
+        starts = list(range(0, n_mine, self.ce_pairs_per_batch))
+        heads = sorted_len[torch.tensor(starts, device=dev)].cpu().tolist()
+        for s0, longest in zip(starts, heads):
+            s1 = min(s0 + self.ce_pairs_per_batch, n_mine)
+            if longest <= 0:
+                continue                               # only empty slots (row -1) left
+            seq = max(8, (int(longest) + 7) // 8 * 8)
+            idx = order[s0:s1]
+            ids, types, mask = rag_hip.ce_pack_dev(
+                q_tok, q_off, store.tok, store.off, store.row_base, my_q[idx].contiguous(),
+                my_r[idx].contiguous(), None, s1 - s0, seq, self.cls_id, self.sep_id, self.pad_id)
+            out = self.cross_encoder(ids, types, mask)
+            logits_mine[idx] = out.float()
+
+    def _ce_packed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+        """Pairs in their own order as one unpadded token stream per mini-batch: no padding is
+        computed at all (bfloat16 model, librag_hip encoder kernels)."""
+        store = self.chunk_tokens
+        n_mine = my_r.shape[0]
+        per = self.ce_pairs_per_batch
+        starts = list(range(0, n_mine, per))
+        # token count and longest pair of every mini-batch: one small copy to the host
+        pad = (-n_mine) % per
+        grid = torch.nn.functional.pad(plen, (0, pad)).view(-1, per)
+        sizes = torch.stack([grid.sum(dim=1), grid.max(dim=1).values]).cpu().tolist()
+        for bi, s0 in enumerate(starts):
+            s1 = min(s0 + per, n_mine)
+            total, longest = int(sizes[0][bi]), int(sizes[1][bi])
+            if total == 0:
+                continue
+            lens = plen[s0:s1]
+            live = lens > 0                              # empty slots (row -1) have no tokens
+            cu = torch.zeros((s1 - s0 + 1,), dtype=torch.int32, device=lens.device)
+            cu[1:] = torch.cumsum(lens, 0)
+            ids, types, pos = rag_hip.ce_pack_packed_dev(q_tok, q_off, store.tok, store.off, store.row_base,
+                                                         my_q[s0:s1], my_r[s0:s1], cu, total, self.ce_max_len,
+                                                         self.cls_id, self.sep_id)
+            if bool(live.all()):
+                logits_mine[s0:s1] = self.cross_encoder.forward_packed(ids, types, pos, cu, longest)
+            else:
+                keep = torch.nonzero(live)[:, 0]
+                cu_live = torch.cat([cu[:-1][keep], cu[-1:]])   # empty pairs add nothing to the sum
+                logits_mine[s0 + keep] = self.cross_encoder.forward_packed(ids, types, pos, cu_live, longest)
 
     # ---- whole path ------------------------------------------------------------------
     def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):

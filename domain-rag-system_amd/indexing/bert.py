@@ -130,6 +130,27 @@ class BertEncoder(nn.Module):
         return x
 
 
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
+        """Unpadded batch on the GPU: ids/types/pos int32 [T], sequence i = tokens
+        [cu_seqlens[i], cu_seqlens[i+1]).  Returns hidden states [T, H].  Everything between
+        the GEMMs runs in librag_hip kernels (bfloat16 weights only)."""
+        import rag_hip
+        c = self.config
+        if not rag_hip.enc_attention_supported(self.word.weight.dtype, c.hidden_size // c.num_attention_heads,
+                                               max_seq_len):
+            raise ValueError("the packed encoder path needs bfloat16 weights, head size 32 or 64 and "
+                             f"sequences up to {rag_hip.ENC_MAX_SEQ} tokens")
+        x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
+                                            self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
+                                            self.emb_norm.eps)
+        for l in self.layers:
+            ctx = rag_hip.enc_attention_packed_dev(l.qkv(x), cu_seqlens, max_seq_len, l.heads)
+            x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps)
+            x = rag_hip.enc_add_layernorm_dev(l.ffn_out(F.gelu(l.ffn_in(x))), x, l.ffn_norm.weight, l.ffn_norm.bias,
+                                              l.ffn_norm.eps)
+        return x
+
+
 class BiEncoder(nn.Module):
     """BERT -> mean pooling over real tokens -> (optional) L2 normalisation."""
 
@@ -159,6 +180,12 @@ class CrossEncoderModel(nn.Module):
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         h = self.bert(input_ids, token_type_ids, attention_mask)
         logits = self.classifier(torch.tanh(self.pooler(h[:, 0])))
+        return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
+
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
+        """Logits of an unpadded batch (every sequence non-empty, first token [CLS])."""
+        h = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)
+        logits = self.classifier(torch.tanh(self.pooler(h[cu_seqlens[:-1].long()])))
         return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
 
 

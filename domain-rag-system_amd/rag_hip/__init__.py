@@ -64,6 +64,11 @@ SIGNATURES = {
                                _i32, _vp, _vp, _vp, _vp]),
     'rag_ce_pair_len_dev': (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_dev': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
+                                           _i32, _i32, _vp, _vp]),
+    'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
+                                      _i32, _vp, _vp, _vp, _vp]),
     'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
 }
 
@@ -150,7 +155,7 @@ def _ptr(t, dtype=None):
 FAULT_NAMES = {1: 'dense candidate list overflow', 2: 'merge selection short', 4: 'bm25 tile list overflow',
                8: 'bm25 posting outside its tile', 16: 'bm25 term id beyond the vocabulary',
                32: 'fusion row outside the canon table', 64: 'cross-encoder pair out of range',
-               128: 'segment offsets out of range'}
+               128: 'segment offsets out of range', 256: 'token, position or type id outside its embedding table'}
 
 
 def fault_flags(clear=True):
@@ -579,3 +584,57 @@ def enc_add_layernorm_dev(x, residual, gamma, beta, eps):
                                           float(eps), rows, hidden, DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32,
                                           _ptr(out), _stream()), 'rag_enc_add_layernorm_dev')
     return out
+
+
+def enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, n_heads):
+    """Packed batch: qkv [T, 3*H] bf16, cu_seqlens [n_seq + 1] int32 -> context [T, H]
+    (rag_enc_attention_packed_dev)."""
+    import torch
+    t, h3 = qkv.shape
+    hidden = h3 // 3
+    out = torch.empty((t, hidden), dtype=qkv.dtype, device=qkv.device)
+    n_seq = cu_seqlens.shape[0] - 1
+    check(lib().rag_enc_attention_packed_dev(_ptr(qkv, torch.bfloat16), _ptr(cu_seqlens, torch.int32), n_seq, t,
+                                             int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
+                                             _ptr(out), _stream()), 'rag_enc_attention_packed_dev')
+    return out
+
+
+def enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, beta, eps):
+    """LayerNorm(word[ids] + position[pos] + type_emb[types]) for a flat token list
+    (rag_enc_embed_layernorm_dev); ids/types/pos int32 [T]."""
+    import torch
+    t = ids.shape[0]
+    hidden = word.shape[1]
+    dt = word.dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise ValueError("enc_embed_layernorm_dev handles bfloat16 and float32 tables")
+    if tuple(pos.shape) != (t,) or (types is not None and tuple(types.shape) != (t,)):
+        raise ValueError("ids, types and pos must have one entry per token")
+    out = torch.empty((t, hidden), dtype=dt, device=ids.device)
+    check(lib().rag_enc_embed_layernorm_dev(_ptr(ids, torch.int32), _ptr(types, torch.int32), _ptr(pos, torch.int32),
+                                            _ptr(word), _ptr(position, dt), _ptr(type_emb, dt), _ptr(gamma, dt),
+                                            _ptr(beta, dt), float(eps), t, hidden, word.shape[0], position.shape[0],
+                                            type_emb.shape[0], DTYPE_BF16 if dt == torch.bfloat16 else DTYPE_F32,
+                                            _ptr(out), _stream()), 'rag_enc_embed_layernorm_dev')
+    return out
+
+
+def ce_pack_packed_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair_query, pair_row, cu,
+                       total_tokens, max_len, cls_id=101, sep_id=102):
+    """Unpadded token stream of the pairs: (ids, types, positions) int32 [total_tokens]
+    (rag_ce_pack_packed_dev); cu [n_pairs + 1] int32 = running sum of ce_pair_len_dev."""
+    import torch
+    n = pair_row.shape[0]
+    if tuple(pair_query.shape) != (n,) or tuple(cu.shape) != (n + 1,):
+        raise ValueError("pair_query / pair_row need one entry per pair and cu one more")
+    dev = pair_row.device
+    ids = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
+    types = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
+    pos = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
+    check(lib().rag_ce_pack_packed_dev(_ptr(query_tok, torch.int32), _ptr(query_off, torch.int64), query_off.shape[0] - 1,
+                                       _ptr(chunk_tok, torch.int32), _ptr(chunk_off, torch.int64), chunk_off.shape[0] - 1,
+                                       int(chunk_row_base), _ptr(pair_query, torch.int32), _ptr(pair_row, torch.int64),
+                                       _ptr(cu, torch.int32), n, int(total_tokens), int(max_len), int(cls_id), int(sep_id),
+                                       _ptr(ids), _ptr(types), _ptr(pos), _stream()), 'rag_ce_pack_packed_dev')
+    return ids, types, pos

@@ -76,6 +76,7 @@ int rag_version(void);
 #define RAG_FAULT_FUSE_ROW     32u  /* fusion: row id outside the canon table                 */
 #define RAG_FAULT_CE_PAIR      64u  /* pair packing: query, chunk row or slot out of range    */
 #define RAG_FAULT_SEGMENT     128u  /* segmented top-k: offsets not ascending / out of range   */
+#define RAG_FAULT_TOKEN       256u  /* embedding lookup: token, position or type id out of range */
 int rag_fault_flags(uint32_t* out_flags, int32_t clear);
 
 /* ---- dense exact kNN ----------------------------------------------------------
@@ -216,6 +217,18 @@ int rag_ce_pack_dev(const int32_t* d_query_tok, const int64_t* d_query_off, int3
                     int32_t cls_id, int32_t sep_id, int32_t pad_id,
                     int64_t* d_input_ids, int64_t* d_token_type_ids, int64_t* d_attention_mask,
                     void* stream);
+/* The same pairs without padding: pair p occupies tokens [cu[p], cu[p+1]) of the
+ * [total_tokens] outputs (input ids, token type ids, positions 0..len-1; int32), where
+ * cu is the running sum of rag_ce_pair_len_dev's lengths for max_len (pairs with
+ * pair_row < 0 have length 0).  A pair whose slice disagrees with its length is skipped
+ * and flagged.                                                                         */
+int rag_ce_pack_packed_dev(const int32_t* d_query_tok, const int64_t* d_query_off, int32_t n_queries,
+                           const int32_t* d_chunk_tok, const int64_t* d_chunk_off, int64_t n_chunks,
+                           int64_t chunk_row_base, const int32_t* d_pair_query,
+                           const int64_t* d_pair_row, const int32_t* d_cu, int32_t n_pairs,
+                           int64_t total_tokens, int32_t max_len, int32_t cls_id, int32_t sep_id,
+                           int32_t* d_input_ids, int32_t* d_token_type_ids, int32_t* d_positions,
+                           void* stream);
 /* Length of each pair as rag_ce_pack_dev would write it (before padding, capped at
  * max_len); used to sort pairs into length buckets.                                */
 int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int64_t* d_chunk_off,
@@ -240,6 +253,21 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
  * padding are zero.  bf16 only; head_dim 32 or 64.                                      */
 int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
                           int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* The same for a PACKED batch: no padding, sequence i owns token rows
+ * [cu_seqlens[i], cu_seqlens[i+1]) of qkv [total_tokens][3][n_heads][head_dim] and of out;
+ * max_seq_len bounds every sequence; a sequence longer than that or reaching beyond
+ * total_tokens is skipped and flagged (RAG_FAULT_SEGMENT).                              */
+int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
+                                 int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                 int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* BERT's input embedding: out[t] = LayerNorm(word[ids[t]] + position[pos[t]] +
+ * type_emb[types[t]]) (types NULL = all 0), tables [vocab|max_pos|n_types][hidden];
+ * ids outside a table are clamped and flagged (RAG_FAULT_TOKEN).                        */
+int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
+                                const void* d_word, const void* d_position, const void* d_type_emb,
+                                const void* d_gamma, const void* d_beta, float eps, int64_t n_tokens,
+                                int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
+                                int32_t dtype, void* d_out, void* stream);
 /* out[r] = LayerNorm(x[r] + residual[r]) * gamma + beta over `hidden` elements per row
  * (residual may be NULL); fp32 arithmetic, inputs/outputs bf16 or fp32 as `dtype` says;
  * hidden a multiple of 8 up to 2048.  out may alias x or residual.                     */

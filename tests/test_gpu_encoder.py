@@ -100,3 +100,84 @@ def test_cross_encoder_with_native_kernels_tracks_fp32():
     spread = float(a.std())
     # the kernels keep more of the arithmetic in fp32 than the PyTorch bf16 ops do
     assert err_native <= max(1.5 * err_plain, 0.02 * spread + 1e-3), (err_native, err_plain, spread)
+
+
+def test_embed_layernorm_matches_reference():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(11)
+    for dtype, tol in ((torch.bfloat16, 3e-2), (torch.float32, 2e-5)):
+        word = torch.randn((500, 384), generator=g, device=dev).to(dtype)
+        position = torch.randn((64, 384), generator=g, device=dev).to(dtype)
+        type_emb = torch.randn((2, 384), generator=g, device=dev).to(dtype)
+        gamma = (1 + 0.1 * torch.randn((384,), generator=g, device=dev)).to(dtype)
+        beta = (0.1 * torch.randn((384,), generator=g, device=dev)).to(dtype)
+        ids = torch.randint(0, 500, (777,), generator=g, device=dev, dtype=torch.int32)
+        pos = torch.randint(0, 64, (777,), generator=g, device=dev, dtype=torch.int32)
+        types = torch.randint(0, 2, (777,), generator=g, device=dev, dtype=torch.int32)
+        out = rag_hip.enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, beta, 1e-12).float()
+        v = word.double()[ids.long()] + position.double()[pos.long()] + type_emb.double()[types.long()]
+        ref = torch.nn.functional.layer_norm(v, (384,), gamma.double(), beta.double(), 1e-12)
+        assert float((out - ref).abs().max()) < tol
+    # an id beyond the table is clamped and reported, not read
+    ids[5] = 10 ** 6
+    rag_hip.enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, beta, 1e-12)
+    assert rag_hip.fault_flags() == 256
+
+
+def test_packed_attention_equals_padded():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(21)
+    b, s, heads, d = 40, 130, 12, 32
+    qkv = torch.randn((b, s, 3 * heads * d), generator=g, device=dev).to(torch.bfloat16)
+    lens = torch.randint(1, s + 1, (b,), generator=g, device=dev, dtype=torch.int32)
+    padded = rag_hip.enc_attention_dev(qkv, lens, heads)
+    cu = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    keep = torch.arange(s, device=dev)[None, :] < lens[:, None]
+    packed = rag_hip.enc_attention_packed_dev(qkv[keep].contiguous(), cu, int(lens.max()), heads)
+    torch.cuda.synchronize()
+    assert torch.equal(packed, padded[keep])
+    # offsets that do not describe the batch are reported and the sequence is skipped
+    cu[-1] += 5
+    rag_hip.enc_attention_packed_dev(qkv[keep].contiguous(), cu, int(lens.max()) + 5, heads)
+    assert rag_hip.fault_flags() == 128
+
+
+def test_packed_pairs_match_padded_pairs_and_logits():
+    import rag_hip
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    nq, nc = 9, 50
+    qlen = rng.integers(3, 20, nq)
+    clen = rng.integers(1, 90, nc)
+    q_off = torch.from_numpy(np.concatenate([[0], np.cumsum(qlen)]).astype(np.int64)).to(dev)
+    c_off = torch.from_numpy(np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)).to(dev)
+    q_tok = torch.from_numpy(rng.integers(1000, 30000, int(qlen.sum())).astype(np.int32)).to(dev)
+    c_tok = torch.from_numpy(rng.integers(1000, 30000, int(clen.sum())).astype(np.int32)).to(dev)
+    n = 300
+    pair_q = torch.from_numpy(rng.integers(0, nq, n).astype(np.int32)).to(dev)
+    pair_r = torch.from_numpy(rng.integers(0, nc, n).astype(np.int64)).to(dev) + 7     # row base 7
+    pair_r[::17] = -1                                                                    # empty slots
+    max_len = 64                                                                         # truncates some chunks
+    plen = rag_hip.ce_pair_len_dev(q_off, c_off, 7, pair_q, pair_r, max_len)
+    cu = torch.zeros((n + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(plen, 0)
+    total = int(cu[-1])
+    ids, types, pos = rag_hip.ce_pack_packed_dev(q_tok, q_off, c_tok, c_off, 7, pair_q, pair_r, cu, total, max_len)
+    pid, ptyp, pmask = rag_hip.ce_pack_dev(q_tok, q_off, c_tok, c_off, 7, pair_q, pair_r, None, n, max_len)
+    keep = pmask.bool()
+    assert torch.equal(pmask.sum(dim=1).int(), plen)
+    assert torch.equal(ids.long(), pid[keep]) and torch.equal(types.long(), ptyp[keep])
+    assert torch.equal(pos.long(), (torch.cumsum(pmask, 1) - 1)[keep])
+    # the same logits from the unpadded stream as from the padded batch (same kernels, same math)
+    model, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.bfloat16, native=True)
+    live = torch.nonzero(plen > 0)[:, 0]
+    cu_live = torch.cat([cu[:-1][live], cu[-1:]])
+    with torch.no_grad():
+        packed = model.forward_packed(ids, types, pos, cu_live, int(plen.max()))
+        padded = model(pid[live], ptyp[live], pmask[live])
+    torch.cuda.synchronize()
+    assert float((packed - padded).abs().max()) < 2e-2 * max(1.0, float(padded.abs().max()))
