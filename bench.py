@@ -44,6 +44,10 @@ def parse():
     ap.add_argument('--ce-dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--ce-pairs-per-batch', type=int, default=16384,
                     help='pairs per cross-encoder forward (an unpadded token stream when the model runs the librag_hip kernels)')
+    ap.add_argument('--tune-gemms', default=None, metavar='FILE',
+                    help='measure hipBLASLt solutions for the encoder GEMM shapes of this workload and write the '
+                         'table to FILE (slow; the default run only reads the table shipped with the package)')
+    ap.add_argument('--no-gemm-table', action='store_true', help='ignore the shipped hipBLASLt solution table')
     ap.add_argument('--ce-torch-ops', action='store_true',
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
@@ -223,6 +227,14 @@ def main():
     from indexing import bert
     from indexing.batch import BatchSearcher, TokenStore
 
+    from indexing import gemm_tuning
+    tuned = False
+    if args.tune_gemms:
+        tuned = gemm_tuning.enable(tune=True, table=args.tune_gemms)
+    elif not args.no_gemm_table:
+        tuned = gemm_tuning.enable(tune=False)
+    log(f'[rank {rank}] hipBLASLt solution table: ' + ('tuning into ' + args.tune_gemms if args.tune_gemms
+                                                      else 'in use' if tuned else 'not used'))
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
     bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev)
     ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
@@ -233,6 +245,8 @@ def main():
                              rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
+    if args.tune_gemms and searcher.ce_packed:
+        gemm_tuning.tune_cross_encoder(ce, searcher.ce_tokens_per_batch, searcher.ce_token_bucket)
 
     def step(q):
         return searcher.search(q['ids'], q['mask'], q['qterms'], q['qoff'], q['n_terms'], q['ce_tok'], q['ce_off'])
@@ -327,6 +341,7 @@ def main():
                    'chunk_tokens': lambda rs: [tok_h[off_h[r]:off_h[r + 1]].tolist() for r in rs]}
         result['cpu_baseline'] = cpu_baseline(args, (bi_cpu, ce_cpu), rows, host, queries[0], gpu_out)
     rag_hip.check_faults()          # every device-side consistency check held during the run
+    result['config']['gemm_solution_table'] = bool(tuned)
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

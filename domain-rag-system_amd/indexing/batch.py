@@ -18,6 +18,7 @@ equals the unsharded one.
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 
 import rag_hip
@@ -49,13 +50,14 @@ class BatchSearcher:
                  chunk_tokens: Optional[TokenStore] = None, top_k: int = 5, rerank_top_n: int = 50,
                  fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
                  ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None,
-                 ce_packed=None):
+                 ce_packed=None, ce_tokens_per_batch: int = 1 << 20, ce_token_bucket: int = 1 << 17):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
         self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
         self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
         # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
+        self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
             and next(cross_encoder.parameters()).dtype == torch.bfloat16)
@@ -183,34 +185,40 @@ class BatchSearcher:
             logits_mine[idx] = out.float()
 
     def _ce_packed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
-        """Pairs in their own order as one unpadded token stream per mini-batch: no padding is
-        computed at all (bfloat16 model, librag_hip encoder kernels)."""
+        """Pairs in their own order as unpadded token streams: no padding inside a pair is
+        computed at all (bfloat16 model, librag_hip encoder kernels).  The stream is cut at
+        pair boundaries into mini-batches of at most `ce_tokens_per_batch` tokens, each rounded
+        up to a multiple of `ce_token_bucket` with unused tail tokens, so the GEMMs see only a
+        handful of distinct shapes (which is what lets hipBLASLt solutions be chosen per shape
+        ahead of time)."""
         store = self.chunk_tokens
         n_mine = my_r.shape[0]
-        per = self.ce_pairs_per_batch
-        starts = list(range(0, n_mine, per))
-        # token count and longest pair of every mini-batch: one small copy to the host
-        pad = (-n_mine) % per
-        grid = torch.nn.functional.pad(plen, (0, pad)).view(-1, per)
-        sizes = torch.stack([grid.sum(dim=1), grid.max(dim=1).values]).cpu().tolist()
-        for bi, s0 in enumerate(starts):
-            s1 = min(s0 + per, n_mine)
-            total, longest = int(sizes[0][bi]), int(sizes[1][bi])
-            if total == 0:
-                continue
-            lens = plen[s0:s1]
-            live = lens > 0                              # empty slots (row -1) have no tokens
-            cu = torch.zeros((s1 - s0 + 1,), dtype=torch.int32, device=lens.device)
-            cu[1:] = torch.cumsum(lens, 0)
-            ids, types, pos = rag_hip.ce_pack_packed_dev(q_tok, q_off, store.tok, store.off, store.row_base,
-                                                         my_q[s0:s1], my_r[s0:s1], cu, total, self.ce_max_len,
-                                                         self.cls_id, self.sep_id)
-            if bool(live.all()):
-                logits_mine[s0:s1] = self.cross_encoder.forward_packed(ids, types, pos, cu, longest)
-            else:
-                keep = torch.nonzero(live)[:, 0]
-                cu_live = torch.cat([cu[:-1][keep], cu[-1:]])   # empty pairs add nothing to the sum
-                logits_mine[s0 + keep] = self.cross_encoder.forward_packed(ids, types, pos, cu_live, longest)
+        dev = my_r.device
+        cu_all = torch.zeros((n_mine + 1,), dtype=torch.int64, device=dev)
+        cu_all[1:] = torch.cumsum(plen, 0)
+        cu_host = cu_all.cpu().numpy()                   # the one host copy of the stage
+        budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
+        p0 = 0
+        while p0 < n_mine:
+            # as many whole pairs as fit the token budget (a single pair always fits: budget >> max_len)
+            p1 = int(np.searchsorted(cu_host, cu_host[p0] + budget, side='right')) - 1
+            p1 = min(max(p1, p0 + 1), n_mine)
+            total = int(cu_host[p1] - cu_host[p0])
+            if total > 0:
+                lens = plen[p0:p1]
+                longest = int((cu_host[p0 + 1:p1 + 1] - cu_host[p0:p1]).max())
+                cu = (cu_all[p0:p1 + 1] - cu_all[p0]).to(torch.int32)
+                padded = (total + bucket - 1) // bucket * bucket
+                ids, types, pos = rag_hip.ce_pack_packed_dev(q_tok, q_off, store.tok, store.off, store.row_base,
+                                                             my_q[p0:p1], my_r[p0:p1], cu, total, self.ce_max_len,
+                                                             self.cls_id, self.sep_id, padded_total=padded)
+                if int(np.count_nonzero(cu_host[p0 + 1:p1 + 1] == cu_host[p0:p1])) == 0:
+                    logits_mine[p0:p1] = self.cross_encoder.forward_packed(ids, types, pos, cu, longest)
+                else:                                    # empty slots (row -1) have no tokens and no logit
+                    keep = torch.nonzero(lens > 0)[:, 0]
+                    cu_live = torch.cat([cu[:-1][keep], cu[-1:]])
+                    logits_mine[p0 + keep] = self.cross_encoder.forward_packed(ids, types, pos, cu_live, longest)
+            p0 = p1
 
     # ---- whole path ------------------------------------------------------------------
     def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):

@@ -621,7 +621,7 @@ def enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, be
 
 
 def ce_pack_packed_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair_query, pair_row, cu,
-                       total_tokens, max_len, cls_id=101, sep_id=102):
+                       total_tokens, max_len, cls_id=101, sep_id=102, padded_total=None):
     """Unpadded token stream of the pairs: (ids, types, positions) int32 [total_tokens]
     (rag_ce_pack_packed_dev); cu [n_pairs + 1] int32 = running sum of ce_pair_len_dev."""
     import torch
@@ -629,9 +629,13 @@ def ce_pack_packed_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_bas
     if tuple(pair_query.shape) != (n,) or tuple(cu.shape) != (n + 1,):
         raise ValueError("pair_query / pair_row need one entry per pair and cu one more")
     dev = pair_row.device
-    ids = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
-    types = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
-    pos = torch.empty((total_tokens,), dtype=torch.int32, device=dev)
+    # outputs may carry unused tail tokens (id 0, position 0) up to `padded_total`
+    size = int(total_tokens if padded_total is None else padded_total)
+    if size < total_tokens:
+        raise ValueError("padded_total is smaller than total_tokens")
+    ids = torch.zeros((size,), dtype=torch.int32, device=dev)
+    types = torch.zeros((size,), dtype=torch.int32, device=dev)
+    pos = torch.zeros((size,), dtype=torch.int32, device=dev)
     check(lib().rag_ce_pack_packed_dev(_ptr(query_tok, torch.int32), _ptr(query_off, torch.int64), query_off.shape[0] - 1,
                                        _ptr(chunk_tok, torch.int32), _ptr(chunk_off, torch.int64), chunk_off.shape[0] - 1,
                                        int(chunk_row_base), _ptr(pair_query, torch.int32), _ptr(pair_row, torch.int64),
