@@ -48,6 +48,10 @@ def parse():
                     help='measure hipBLASLt solutions for the encoder GEMM shapes of this workload and write the '
                          'table to FILE (slow; the default run only reads the table shipped with the package)')
     ap.add_argument('--no-gemm-table', action='store_true', help='ignore the shipped hipBLASLt solution table')
+    ap.add_argument('--embed-torch-ops', action='store_true',
+                    help='run the embedder on padded batches with PyTorch ops instead of the unpadded librag_hip path')
+    ap.add_argument('--embed-fp32-gemm', action='store_true',
+                    help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
     ap.add_argument('--ce-torch-ops', action='store_true',
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
@@ -236,7 +240,8 @@ def main():
     log(f'[rank {rank}] hipBLASLt solution table: ' + ('tuning into ' + args.tune_gemms if args.tune_gemms
                                                       else 'in use' if tuned else 'not used'))
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
-    bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev)
+    bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev, native=not args.embed_torch_ops,
+                               split_gemm=not args.embed_fp32_gemm)
     ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
     ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype,
                                native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
@@ -313,7 +318,9 @@ def main():
         'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s (cross-encoder forward) / f32 (embedder forward)' % args.ce_dtype,
+        'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s (cross-encoder forward) / %s' % (
+            args.ce_dtype, 'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else
+            'f32 embedder forward with GEMMs as 3 split-bf16 MFMA products, fp32 accumulation (cosine within 1e-5 of fp32)'),
         'data': 'synthetic (seeded random unit vectors, Zipf postings, random token ids, random-init weights)',
         'config': {'workload': '%dM x %d corpus%s, hybrid vector+BM25, RRF, MiniLM-L6 cross-encoder rerank_top_n=%d, '
                                'top_k=%d' % (n_total // 1_000_000, args.dim,

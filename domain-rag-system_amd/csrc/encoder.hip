@@ -23,6 +23,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int ATT_NT = 256;          // 4 waves; each takes 32-query blocks round-robin
 constexpr float NEG_BIG = -1e30f;    // finite stand-in for -inf (keeps max/exp free of NaN)
 
+// 8-element vector access for the row kernels
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    typedef bf16x8 type;
+    __device__ static void load(const bf16* p, float* f) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    __device__ static void store(bf16* p, const float* f) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+template <> struct Vec8<float> {
+    __device__ static void load(const float* p, float* f) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    __device__ static void store(float* p, const float* f) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+
+constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes up to 2048
+
 // LDS image of one head's keys and values:
 //   K   [kpad][D + 8]     rows padded by 16 B: the 16-byte operand reads of 32 keys spread over the banks
 //   V^T [D][kpad + 4]     rows padded by 8 B: 32 lanes read 8 B of 32 different d rows without conflict
@@ -30,15 +59,22 @@ template <int D>
 __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restrict__ qkv,
                                                            const int32_t* __restrict__ lens,
                                                            const int32_t* __restrict__ cu, int64_t total_tokens,
-                                                           int S_max, int NH, float scale, bf16* __restrict__ out,
-                                                           uint32_t* fault) {
+                                                           int n_seq, int S_max, int NH, float scale,
+                                                           bf16* __restrict__ out, uint32_t* fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KROW = D + 8;
     constexpr int DT = D / 32;                    // 32-row tiles of the transposed output
     constexpr int KC = D / 16;                    // k-steps of the score product
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int seq = blockIdx.x / NH, head = blockIdx.x - seq * NH;
+    // The heads of one sequence interleave in memory (a head's 64- or 128-byte slice of a token
+    // shares its cache lines with the neighbouring heads), so all heads of a sequence go to
+    // workgroups with the same blockIdx % 8, which round-robin placement puts on one XCD: the
+    // lines are then fetched into one L2 once instead of into several.
+    const int jb = blockIdx.x >> 3;
+    const int head = jb % NH;
+    const int seq = (jb / NH) * 8 + (blockIdx.x & 7);
+    if (seq >= n_seq) return;
     const int H = NH * D;
     const size_t tok = (size_t)3 * H;             // elements per token of the projection output
     // padded batch: sequence i owns rows [i*S_max, (i+1)*S_max), lens[i] of them real;
@@ -183,34 +219,169 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
     }
 }
 
-// ---- LayerNorm(x + residual) ---------------------------------------------------------------
-template <typename T> struct Vec8;
-template <> struct Vec8<bf16> {
-    typedef bf16x8 type;
-    __device__ static void load(const bf16* p, float* f) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+// fp32 attention for the bi-encoder (its embeddings must hold 1e-4 on cosine scores, so its
+// forward stays in fp32): one wave per (sequence, head), one query row per lane, keys and values
+// of 64-key chunks broadcast from LDS, two-pass softmax per chunk with a running maximum.
+// The arithmetic is tiny next to the GEMMs (a few GFLOP per batch); plain FMAs, no MFMA.
+template <int D>
+__global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv,
+                                                           const int32_t* __restrict__ lens,
+                                                           const int32_t* __restrict__ cu, int64_t total_tokens,
+                                                           int n_seq, int S_max, int NH, float scale,
+                                                           float* __restrict__ out, uint32_t* fault) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][D];
+    __shared__ __attribute__((aligned(16))) float Vs[64][D];
+    const int lane = threadIdx.x;
+    const int jb = blockIdx.x >> 3;
+    const int head = jb % NH;
+    const int seq = (jb / NH) * 8 + (blockIdx.x & 7);
+    if (seq >= n_seq) return;
+    const int H = NH * D;
+    const size_t tok = (size_t)3 * H;
+    int64_t first;
+    int S, len;
+    if (cu != nullptr) {
+        first = cu[seq];
+        const int64_t n = (int64_t)cu[seq + 1] - first;
+        if (first < 0 || n < 0 || n > S_max || first + n > total_tokens) {
+            if (lane == 0) rag_flag(fault, RAG_FAULT_SEGMENT);
+            return;
+        }
+        len = (int)n;
+        S = len;
+    } else {
+        first = (int64_t)seq * S_max;
+        S = S_max;
+        len = min(max(lens[seq], 0), S);
     }
-    __device__ static void store(bf16* p, const float* f) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
-        *reinterpret_cast<bf16x8*>(p) = v;
-    }
-};
-template <> struct Vec8<float> {
-    __device__ static void load(const float* p, float* f) {
-        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-    }
-    __device__ static void store(float* p, const float* f) {
-        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
-    }
-};
+    const float* base = qkv + (size_t)first * tok + head * D;
+    float* obase = out + (size_t)first * H + head * D;
 
-constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes up to 2048
+    for (int q0 = 0; q0 < S; q0 += 64) {
+        const int q = q0 + lane;
+        const bool live = q < S && len > 0;
+        float qv[D], o[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { qv[d] = 0.f; o[d] = 0.f; }
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * tok + d);
+                qv[d] = v.x * scale; qv[d + 1] = v.y * scale; qv[d + 2] = v.z * scale; qv[d + 3] = v.w * scale;
+            }
+        }
+        float m_run = NEG_BIG, l_run = 0.f;
+        for (int k0 = 0; k0 < len; k0 += 64) {
+            const int nk = min(64, len - k0);
+            __syncthreads();                              // the previous chunk has been consumed
+            const int nk16 = (nk + 15) & ~15;             // rows up to the next 16 are read: zero them
+            for (int i = lane; i < nk16 * (D / 4); i += 64) {
+                const int key = i / (D / 4), c = i - key * (D / 4);
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                if (key < nk) {
+                    const float* p = base + (size_t)(k0 + key) * tok + c * 4;
+                    kv = *reinterpret_cast<const float4*>(p + H);
+                    vv = *reinterpret_cast<const float4*>(p + 2 * H);
+                }
+                *reinterpret_cast<float4*>(&Ks[key][c * 4]) = kv;
+                *reinterpret_cast<float4*>(&Vs[key][c * 4]) = vv;
+            }
+            __syncthreads();
+            for (int kb = 0; kb < nk; kb += 16) {
+                float sc[16];
+                float mx = NEG_BIG;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; d += 4) {
+                        const float4 kv = *reinterpret_cast<const float4*>(&Ks[kb + k][d]);
+                        a += qv[d] * kv.x + qv[d + 1] * kv.y + qv[d + 2] * kv.z + qv[d + 3] * kv.w;
+                    }
+                    sc[k] = kb + k < nk ? a : NEG_BIG;
+                    mx = fmaxf(mx, sc[k]);
+                }
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = expf(m_run - m_new);
+#pragma unroll
+                for (int d = 0; d < D; ++d) o[d] *= alpha;
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float pk = kb + k < nk ? expf(sc[k] - m_new) : 0.f;
+                    sum += pk;
+#pragma unroll
+                    for (int d = 0; d < D; d += 4) {
+                        const float4 vv = *reinterpret_cast<const float4*>(&Vs[kb + k][d]);
+                        o[d] += pk * vv.x; o[d + 1] += pk * vv.y; o[d + 2] += pk * vv.z; o[d + 3] += pk * vv.w;
+                    }
+                }
+                l_run = l_run * alpha + sum;
+                m_run = m_new;
+            }
+        }
+        if (q < S) {
+            const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d += 4)
+                *reinterpret_cast<float4*>(obase + (size_t)q * H + d) =
+                    make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+        }
+    }
+}
+
+// Mean over each sequence's tokens, then (optionally) L2 normalisation: one wave per sequence.
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                        int64_t total_tokens, int n_seq, int H, int normalize,
+                                                        float* __restrict__ out, uint32_t* fault) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= n_seq) return;
+    const int64_t a = cu[seq], b = cu[seq + 1];
+    const int n_chunks = H / 8;
+    float v[LN_MAX_CHUNKS][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    if (a < 0 || b < a || b > total_tokens) {
+        if (lane == 0) rag_flag(fault, RAG_FAULT_SEGMENT);
+    } else {
+        for (int64_t t = a; t < b; ++t) {
+#pragma unroll
+            for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < n_chunks) {
+                    float f[8];
+                    Vec8<float>::load(x + t * H + ch * 8, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[c][j] += f[j];
+                }
+            }
+        }
+    }
+    const float inv_n = b > a ? 1.f / (float)(b - a) : 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[c][j] *= inv_n; sq += v[c][j] * v[c][j]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float sc = normalize ? 1.f / fmaxf(sqrtf(sq), 1e-12f) : 1.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = v[c][j] * sc;
+            Vec8<float>::store(out + (size_t)seq * H + ch * 8, y);
+        }
+    }
+}
+
+// ---- LayerNorm(x + residual) ---------------------------------------------------------------
 
 template <typename T>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res,
@@ -356,19 +527,32 @@ namespace {
 int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
                      int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
     RAG_REQUIRE(n_seq >= 0 && seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention: bad sizes");
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attention: only bf16 is implemented");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_attention: unknown dtype");
     RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention: head_dim must be 32 or 64 (got %d)",
                 head_dim);
     RAG_REQUIRE(seq_len <= RAG_ENC_MAX_SEQ, RAG_ELIMIT, "rag_enc_attention: seq_len %d exceeds %d", seq_len,
                 RAG_ENC_MAX_SEQ);
     if (n_seq == 0) return RAG_OK;
     RAG_REQUIRE(d_qkv && d_out, RAG_EINVAL, "rag_enc_attention: null pointer");
-    RAG_REQUIRE((int64_t)n_seq * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention: too many (sequence, head) pairs");
+    RAG_REQUIRE(((int64_t)n_seq + 8) * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention: too many (sequence, head) pairs");
     hipStream_t stream = (hipStream_t)stream_;
     const int kpad = (seq_len + 31) & ~31;
     const size_t lds = (size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2;
     const float scale = 1.0f / sqrtf((float)head_dim);
-    const unsigned grid = (unsigned)((int64_t)n_seq * n_heads);
+    const unsigned grid = (unsigned)((int64_t)((n_seq + 7) / 8) * 8 * n_heads);
+    if (dtype == RAG_DTYPE_F32) {
+        const float scale32 = 1.0f / sqrtf((float)head_dim);
+        if (head_dim == 32)
+            attention_f32_kernel<32><<<grid, 64, 0, (hipStream_t)stream_>>>((const float*)d_qkv, d_lens, d_cu, total_tokens,
+                                                                           n_seq, seq_len, n_heads, scale32,
+                                                                           (float*)d_out, rag_fault_word());
+        else
+            attention_f32_kernel<64><<<grid, 64, 0, (hipStream_t)stream_>>>((const float*)d_qkv, d_lens, d_cu, total_tokens,
+                                                                           n_seq, seq_len, n_heads, scale32,
+                                                                           (float*)d_out, rag_fault_word());
+        RAG_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
     if (head_dim == 32) {
         static size_t granted = 64 * 1024;
         if (lds > granted) {
@@ -376,8 +560,8 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, seq_len, n_heads,
-                                                            scale, (bf16*)d_out, rag_fault_word());
+        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
+                                                            n_heads, scale, (bf16*)d_out, rag_fault_word());
     } else {
         static size_t granted = 64 * 1024;
         if (lds > granted) {
@@ -385,8 +569,8 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, seq_len, n_heads,
-                                                            scale, (bf16*)d_out, rag_fault_word());
+        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
+                                                            n_heads, scale, (bf16*)d_out, rag_fault_word());
     }
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
@@ -443,6 +627,55 @@ extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* 
                                                                 (const float*)d_gamma, (const float*)d_beta, eps,
                                                                 n_tokens, hidden, vocab, max_pos, n_types,
                                                                 (float*)d_out, rag_fault_word());
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+namespace {
+// x (fp32) = hi + lo + (what is left below 2^-17 relative), hi and lo in bf16; one row of the
+// output is [hi | hi | lo], the left operand of a GEMM against [w_hi ; w_lo ; w_hi].
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, int64_t rows, int K,
+                                                           bf16* __restrict__ out) {
+    const int64_t n8 = rows * (K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / (K / 8);
+        const int c = (int)(i - row * (K / 8));
+        float f[8];
+        Vec8<float>::load(x + row * K + c * 8, f);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (bf16)f[j];
+            lo[j] = (bf16)(f[j] - (float)hi[j]);
+        }
+        bf16* o = out + row * 3 * K + c * 8;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + K) = hi;
+        *reinterpret_cast<bf16x8*>(o + 2 * K) = lo;
+    }
+}
+}  // namespace
+
+extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream_) {
+    RAG_REQUIRE(rows >= 0 && k >= 8 && k % 8 == 0, RAG_EINVAL, "rag_enc_split_bf16x3: k must be a positive multiple of 8");
+    if (rows == 0) return RAG_OK;
+    RAG_REQUIRE(d_x && d_out, RAG_EINVAL, "rag_enc_split_bf16x3: null pointer");
+    const int64_t n8 = rows * (k / 8);
+    const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
+    split_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (bf16*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq, int64_t total_tokens,
+                                     int32_t hidden, int32_t normalize, float* d_out, void* stream_) {
+    RAG_REQUIRE(n_seq >= 0 && total_tokens >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS,
+                RAG_ELIMIT, "rag_enc_mean_pool: hidden must be a multiple of 8 up to %d", 8 * 64 * LN_MAX_CHUNKS);
+    if (n_seq == 0) return RAG_OK;
+    RAG_REQUIRE(d_x && d_cu_seqlens && d_out, RAG_EINVAL, "rag_enc_mean_pool: null pointer");
+    mean_pool_kernel<<<(unsigned)((n_seq + 3) / 4), 256, 0, (hipStream_t)stream_>>>(d_x, d_cu_seqlens, total_tokens, n_seq,
+                                                                                   hidden, normalize, d_out,
+                                                                                   rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

@@ -87,6 +87,10 @@ class BatchSearcher:
     # ---- stages ----------------------------------------------------------------------
     @torch.no_grad()
     def embed(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        if getattr(self.bi_encoder.bert, 'native', False):
+            # unpadded: queries differ a lot in length, and padding positions cost full GEMM rows
+            p_ids, p_types, p_pos, cu, longest = self.bi_encoder.bert.pack(ids, mask)
+            return self.bi_encoder.forward_packed(p_ids, p_types, p_pos, cu, max(longest, 1), normalize=True)
         return self.bi_encoder(ids, None, mask, normalize=True).contiguous()
 
     def _gather_merge(self, score, row, cnt, k):

@@ -101,6 +101,21 @@ class BertEncoder(nn.Module):
         self.emb_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
         self.layers = nn.ModuleList([BertLayer(c) for _ in range(c.num_hidden_layers)])
         self.native = False          # set by load_model(native=True): use the librag_hip encoder kernels
+        self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
+        self._split_cache = {}
+
+    @staticmethod
+    def pack(input_ids, attention_mask, token_type_ids=None):
+        """Padded [B, S] ids + left-aligned mask -> the unpadded stream forward_packed takes:
+        (ids, types, pos int32 [T], cu_seqlens int32 [B+1], longest).  One host round trip."""
+        keep = attention_mask.bool()
+        lens = keep.sum(dim=1)
+        cu = torch.zeros((input_ids.shape[0] + 1,), dtype=torch.int32, device=input_ids.device)
+        cu[1:] = torch.cumsum(lens, 0)
+        pos = torch.arange(input_ids.shape[1], device=input_ids.device, dtype=torch.int32)[None, :].expand_as(input_ids)
+        types = token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids)
+        return (input_ids[keep].to(torch.int32), types[keep].to(torch.int32), pos[keep].contiguous(), cu,
+                int(lens.max()) if lens.numel() else 0)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         b, s = input_ids.shape
@@ -133,22 +148,37 @@ class BertEncoder(nn.Module):
     def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
         """Unpadded batch on the GPU: ids/types/pos int32 [T], sequence i = tokens
         [cu_seqlens[i], cu_seqlens[i+1]).  Returns hidden states [T, H].  Everything between
-        the GEMMs runs in librag_hip kernels (bfloat16 weights only)."""
+        the GEMMs runs in librag_hip kernels (bfloat16 or float32 weights)."""
         import rag_hip
         c = self.config
         if not rag_hip.enc_attention_supported(self.word.weight.dtype, c.hidden_size // c.num_attention_heads,
                                                max_seq_len):
-            raise ValueError("the packed encoder path needs bfloat16 weights, head size 32 or 64 and "
+            raise ValueError("the packed encoder path needs bfloat16 or float32 weights, head size 32 or 64 and "
                              f"sequences up to {rag_hip.ENC_MAX_SEQ} tokens")
         x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
+        lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else (lambda m, v: m(v))
         for l in self.layers:
-            ctx = rag_hip.enc_attention_packed_dev(l.qkv(x), cu_seqlens, max_seq_len, l.heads)
-            x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps)
-            x = rag_hip.enc_add_layernorm_dev(l.ffn_out(F.gelu(l.ffn_in(x))), x, l.ffn_norm.weight, l.ffn_norm.bias,
-                                              l.ffn_norm.eps)
+            ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
+            x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
+                                              l.attn_norm.eps)
+            x = rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, F.gelu(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
+                                              l.ffn_norm.bias, l.ffn_norm.eps)
         return x
+
+    def _linear_split(self, module, x):
+        """fp32 Linear on the bf16 matrix cores: three bf16 products accumulated in fp32 inside one
+        GEMM (operands split into bf16 high and low parts and laid side by side along K).  The
+        result differs from the fp32 GEMM by about 1e-5 relative, far inside the 1e-4 the
+        embeddings have to hold on cosine scores, at a fraction of the fp32 matrix-core time."""
+        import rag_hip
+        w3 = self._split_cache.get(id(module))
+        if w3 is None:
+            w3 = rag_hip.split_weight_bf16x3(module.weight.detach())
+            self._split_cache[id(module)] = w3
+        y = torch.mm(rag_hip.enc_split_bf16x3_dev(x), w3.t(), out_dtype=torch.float32)
+        return y.add_(module.bias)
 
 
 class BiEncoder(nn.Module):
@@ -166,6 +196,13 @@ class BiEncoder(nn.Module):
             m = attention_mask.to(h.dtype)[:, :, None]
             pooled = (h * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
         return F.normalize(pooled, p=2, dim=1) if normalize else pooled
+
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len, normalize=True):
+        """Sentence embeddings of an unpadded batch (float32 weights): no padding position is
+        computed; everything between the GEMMs runs in librag_hip kernels."""
+        import rag_hip
+        h = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)
+        return rag_hip.enc_mean_pool_dev(h.float(), cu_seqlens, normalize)
 
 
 class CrossEncoderModel(nn.Module):
@@ -286,7 +323,7 @@ def _resolve_dir(spec):
             f"({type(e).__name__}); pass a directory or a 'random:<arch>' spec") from e
 
 
-def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False):
+def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False):
     """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config).
     native=True runs attention and residual+LayerNorm through the librag_hip kernels (GPU,
     bfloat16, left-aligned attention masks); shapes they do not cover raise."""
@@ -319,6 +356,7 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False):
         tok = FileTokenizer(directory)
     model.eval().to(device=device, dtype=dtype)
     model.bert.native = bool(native)
+    model.bert.split_gemm = bool(split_gemm)
     return model, tok, cfg
 
 

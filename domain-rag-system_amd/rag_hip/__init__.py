@@ -67,6 +67,8 @@ SIGNATURES = {
     'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
+    'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
                                       _i32, _vp, _vp, _vp, _vp]),
     'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
@@ -550,7 +552,16 @@ def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair
 # ---- transformer encoder pieces ----------------------------------------------------------------
 def enc_attention_supported(dtype, head_dim, seq_len):
     import torch
-    return dtype == torch.bfloat16 and head_dim in (32, 64) and seq_len <= ENC_MAX_SEQ
+    return dtype in (torch.bfloat16, torch.float32) and head_dim in (32, 64) and seq_len <= ENC_MAX_SEQ
+
+
+def _enc_dtype(t):
+    import torch
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    raise ValueError(f"the encoder kernels handle bfloat16 and float32, not {t.dtype}")
 
 
 def enc_attention_dev(qkv, lens, n_heads):
@@ -562,8 +573,8 @@ def enc_attention_dev(qkv, lens, n_heads):
     out = torch.empty((b, s, hidden), dtype=qkv.dtype, device=qkv.device)
     if tuple(lens.shape) != (b,):
         raise ValueError("lens must hold one length per sequence")
-    check(lib().rag_enc_attention_dev(_ptr(qkv, torch.bfloat16), _ptr(lens, torch.int32), b, s, int(n_heads),
-                                      hidden // int(n_heads), DTYPE_BF16, _ptr(out), _stream()),
+    check(lib().rag_enc_attention_dev(_ptr(qkv), _ptr(lens, torch.int32), b, s, int(n_heads),
+                                      hidden // int(n_heads), _enc_dtype(qkv), _ptr(out), _stream()),
           'rag_enc_attention_dev')
     return out
 
@@ -594,8 +605,8 @@ def enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, n_heads):
     hidden = h3 // 3
     out = torch.empty((t, hidden), dtype=qkv.dtype, device=qkv.device)
     n_seq = cu_seqlens.shape[0] - 1
-    check(lib().rag_enc_attention_packed_dev(_ptr(qkv, torch.bfloat16), _ptr(cu_seqlens, torch.int32), n_seq, t,
-                                             int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
+    check(lib().rag_enc_attention_packed_dev(_ptr(qkv), _ptr(cu_seqlens, torch.int32), n_seq, t,
+                                             int(max_seq_len), int(n_heads), hidden // int(n_heads), _enc_dtype(qkv),
                                              _ptr(out), _stream()), 'rag_enc_attention_packed_dev')
     return out
 
@@ -642,3 +653,33 @@ def ce_pack_packed_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_bas
                                        _ptr(cu, torch.int32), n, int(total_tokens), int(max_len), int(cls_id), int(sep_id),
                                        _ptr(ids), _ptr(types), _ptr(pos), _stream()), 'rag_ce_pack_packed_dev')
     return ids, types, pos
+
+
+def enc_mean_pool_dev(x, cu_seqlens, normalize=True):
+    """Per-sequence mean of a packed fp32 batch x [T, H], optionally L2-normalised -> [n_seq, H]
+    (rag_enc_mean_pool_dev)."""
+    import torch
+    t, hidden = x.shape
+    n_seq = cu_seqlens.shape[0] - 1
+    out = torch.empty((n_seq, hidden), dtype=torch.float32, device=x.device)
+    check(lib().rag_enc_mean_pool_dev(_ptr(x, torch.float32), _ptr(cu_seqlens, torch.int32), n_seq, t, hidden,
+                                      1 if normalize else 0, _ptr(out), _stream()), 'rag_enc_mean_pool_dev')
+    return out
+
+
+def enc_split_bf16x3_dev(x):
+    """fp32 [rows, K] -> bf16 [rows, 3K] = [hi | hi | lo] (rag_enc_split_bf16x3_dev)."""
+    import torch
+    rows, k = x.shape
+    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=x.device)
+    check(lib().rag_enc_split_bf16x3_dev(_ptr(x, torch.float32), rows, k, _ptr(out), _stream()),
+          'rag_enc_split_bf16x3_dev')
+    return out
+
+
+def split_weight_bf16x3(w):
+    """fp32 weight [N, K] -> bf16 [N, 3K] = [w_hi | w_lo | w_hi], the partner of enc_split_bf16x3_dev."""
+    import torch
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()

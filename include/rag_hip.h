@@ -250,7 +250,8 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
  * sequence i (keys at or beyond it are masked, as BERT's additive attention mask does);
  * out [n_seq][seq_len][n_heads*head_dim] = softmax(Q K^T / sqrt(head_dim)) V per head.
  * Rows of padding positions are written (finite), rows of 32-row blocks that hold only
- * padding are zero.  bf16 only; head_dim 32 or 64.                                      */
+ * padding are zero.  dtype bf16 (MFMA kernel, fp32 softmax) or fp32 (plain fp32
+ * arithmetic); head_dim 32 or 64.                                                        */
 int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
                           int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
 /* The same for a PACKED batch: no padding, sequence i owns token rows
@@ -260,6 +261,19 @@ int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_se
 int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
                                  int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
                                  int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* Sentence embedding of a packed fp32 batch: out[i] = mean of x over the tokens of
+ * sequence i (the mean pooling over the attention mask of the sentence-transformers
+ * pipeline behind reference src/indexing/embedder.py:65-71), L2-normalised when
+ * `normalize` is non-zero.  x [total_tokens][hidden], out [n_seq][hidden].             */
+int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq,
+                          int64_t total_tokens, int32_t hidden, int32_t normalize, float* d_out,
+                          void* stream);
+/* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32
+ * row x[r][0..k) becomes the bf16 row [hi | hi | lo] of 3k elements (hi = bf16(x),
+ * lo = bf16(x - hi)).  Multiplied (fp32 accumulation) by weights laid out as
+ * [w_hi ; w_lo ; w_hi] along k it yields x_hi w_hi + x_hi w_lo + x_lo w_hi, i.e. the fp32
+ * product to about 2^-16 relative per term (the dropped x_lo w_lo term).               */
+int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream);
 /* BERT's input embedding: out[t] = LayerNorm(word[ids[t]] + position[pos[t]] +
  * type_emb[types[t]]) (types NULL = all 0), tables [vocab|max_pos|n_types][hidden];
  * ids outside a table are clamped and flagged (RAG_FAULT_TOKEN).                        */

@@ -55,7 +55,7 @@ def test_attention_argument_errors():
     with pytest.raises(rag_hip.RagHipError):
         rag_hip.enc_attention_dev(qkv, lens, 3)          # head size 16
     with pytest.raises(ValueError):
-        rag_hip.enc_attention_dev(qkv.float(), lens, 1)
+        rag_hip.enc_attention_dev(qkv.half(), lens, 1)      # fp16 is not covered
     big = torch.zeros((1, 513, 3 * 32), dtype=torch.bfloat16, device=dev)
     with pytest.raises(rag_hip.RagHipError):
         rag_hip.enc_attention_dev(big, lens, 1)
@@ -181,3 +181,71 @@ def test_packed_pairs_match_padded_pairs_and_logits():
         padded = model(pid[live], ptyp[live], pmask[live])
     torch.cuda.synchronize()
     assert float((packed - padded).abs().max()) < 2e-2 * max(1.0, float(padded.abs().max()))
+
+
+@pytest.mark.parametrize('b,s,heads,d', [(6, 26, 12, 64), (3, 150, 4, 32), (2, 70, 2, 64)])
+def test_fp32_attention_matches_reference(b, s, heads, d):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(b + s)
+    qkv = torch.randn((b, s, 3 * heads * d), generator=g, device=dev)
+    lens = torch.randint(1, s + 1, (b,), generator=g, device=dev, dtype=torch.int32)
+    lens[0] = s
+    out = rag_hip.enc_attention_dev(qkv, lens, heads)
+    ref = _ref_attention(qkv.double(), lens, heads)
+    for i in range(b):
+        n = int(lens[i])
+        assert float((out[i, :n].double() - ref[i, :n]).abs().max()) < 2e-6
+    cu = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    keep = torch.arange(s, device=dev)[None, :] < lens[:, None]
+    packed = rag_hip.enc_attention_packed_dev(qkv[keep].contiguous(), cu, int(lens.max()), heads)
+    assert torch.equal(packed, out[keep])
+
+
+def test_packed_fp32_embedder_matches_pytorch_ops():
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    plain, _, cfg = bert.load_model('random:bert-base', 'bi', dev)
+    native, _, _ = bert.load_model('random:bert-base', 'bi', dev, native=True)
+    g = torch.Generator(device=dev).manual_seed(8)
+    b, s = 50, 26
+    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev)
+    lens = torch.randint(3, s + 1, (b,), generator=g, device=dev)
+    mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
+    with torch.no_grad():
+        a = plain(ids, None, mask, normalize=True)
+        p = native.forward_packed(*native.bert.pack(ids, mask), normalize=True)
+    torch.cuda.synchronize()
+    # embeddings are unit vectors: a per-component bound is a bound on any cosine score
+    assert float((a - p).abs().max()) < 2e-5
+    assert float((a * p).sum(dim=1).min()) > 1 - 1e-6
+
+
+def test_split_bf16_gemm_embedder_holds_the_cosine_tolerance():
+    import rag_hip
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn((1000, 768), generator=g, device=dev) * 3
+    w = torch.randn((512, 768), generator=g, device=dev) * 0.05
+    x3 = rag_hip.enc_split_bf16x3_dev(x)
+    hi = x.bfloat16()
+    assert torch.equal(x3[:, :768], hi) and torch.equal(x3[:, 768:1536], hi)
+    assert torch.equal(x3[:, 1536:], (x - hi.float()).bfloat16())
+    y = torch.mm(x3, rag_hip.split_weight_bf16x3(w).t(), out_dtype=torch.float32)
+    ref = x.double() @ w.double().t()
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    plain, _, cfg = bert.load_model('random:bert-base', 'bi', dev)
+    split, _, _ = bert.load_model('random:bert-base', 'bi', dev, native=True, split_gemm=True)
+    b, s = 64, 26
+    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev)
+    lens = torch.randint(3, s + 1, (b,), generator=g, device=dev)
+    mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
+    with torch.no_grad():
+        a = plain(ids, None, mask, normalize=True)
+        p = split.forward_packed(*split.bert.pack(ids, mask), normalize=True)
+    corpus = torch.nn.functional.normalize(torch.randn((50000, 768), generator=g, device=dev), dim=1)
+    # the bar of the path: cosine scores within 1e-4 of the fp32 forward (here: 10x inside it)
+    assert float(((a - p) @ corpus.t()).abs().max()) < 1e-5
+    assert float((a - p).abs().max()) < 2e-5
