@@ -326,7 +326,10 @@ def _resolve_dir(spec):
 def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False):
     """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config).
     native=True runs attention and residual+LayerNorm through the librag_hip kernels (GPU,
-    bfloat16, left-aligned attention masks); shapes they do not cover raise."""
+    bfloat16 or float32, left-aligned attention masks; shapes they do not cover raise);
+    native='auto' does so whenever the model sits on a GPU and has a head size the kernels
+    cover.  split_gemm=True (float32 weights, packed forward) runs the GEMMs as split-bf16
+    products with fp32 accumulation."""
     cls = BiEncoder if kind == 'bi' else CrossEncoderModel
     if spec.startswith('random:'):
         arch = spec.split(':', 1)[1]
@@ -355,6 +358,9 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
             raise RuntimeError(f"checkpoint under {directory} lacks weights: {bad[:5]}")
         tok = FileTokenizer(directory)
     model.eval().to(device=device, dtype=dtype)
+    if native == 'auto':            # on the GPU whenever the kernels cover the architecture
+        native = (torch.device(device).type == 'cuda' and dtype in (torch.bfloat16, torch.float32)
+                  and cfg.hidden_size // cfg.num_attention_heads in (32, 64))
     model.bert.native = bool(native)
     model.bert.split_gemm = bool(split_gemm)
     return model, tok, cfg

@@ -26,7 +26,7 @@ class MedicalEmbedder:
         self.batch_size = batch_size
         self.max_length = max_length
         self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
-        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'bi', self.device, dtype=dtype)
+        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'bi', self.device, dtype=dtype, native='auto')
         self.max_length = min(max_length, cfg.max_position_embeddings)
         self.embedding_dim = cfg.hidden_size
 

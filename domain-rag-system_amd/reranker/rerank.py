@@ -90,7 +90,7 @@ class CrossEncoderReranker(BaseReranker):
                  max_length: int = 512):
         super().__init__(top_n=top_n, name="cross-encoder")
         self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
-        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'cross', self.device, dtype=dtype)
+        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'cross', self.device, dtype=dtype, native='auto')
         self.batch_size = batch_size
         self.max_length = min(max_length, cfg.max_position_embeddings)
 
