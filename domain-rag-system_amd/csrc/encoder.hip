@@ -60,7 +60,9 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
                                                            const int32_t* __restrict__ lens,
                                                            const int32_t* __restrict__ cu, int64_t total_tokens,
                                                            int n_seq, int S_max, int NH, float scale,
-                                                           bf16* __restrict__ out, uint32_t* fault) {
+                                                           int first_only, bf16* __restrict__ out, uint32_t* fault) {
+    // first_only: only the first token of every sequence is a query ([CLS] of the last layer, the
+    // one row the pooler reads); out is then [n_seq][H]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KROW = D + 8;
     constexpr int DT = D / 32;                    // 32-row tiles of the transposed output
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
         len = min(max(lens[seq], 0), S);
     }
     const bf16* base = qkv + (size_t)first * tok;
-    bf16* obase = out + (size_t)first * H + head * D;
+    bf16* obase = first_only ? out + (size_t)seq * H + head * D : out + (size_t)first * H + head * D;
     const int kpad = (len + 31) & ~31;
     const int VROW = kpad + 4;
     bf16* Ks = reinterpret_cast<bf16*>(smem);
@@ -119,13 +121,14 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
     }
     __syncthreads();
 
-    for (int qb = wave; qb * 32 < S; qb += ATT_NT / 64) {
+    const int n_query_rows = first_only ? 1 : S;
+    for (int qb = wave; qb * 32 < n_query_rows; qb += ATT_NT / 64) {
         const int q = qb * 32 + r;
         if (qb * 32 >= len) {
             // padding rows only: defined (zero) output, nothing to compute
             for (int i = lane; i < 32 * (D / 8); i += 64) {
                 const int row = qb * 32 + i / (D / 8), c8 = i % (D / 8);
-                if (row < S) {
+                if (row < n_query_rows) {
                     bf16x8 z;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
         }
         // O^T tile: rows = d (registers + lane half), column = this lane's query
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        if (q < S) {
+        if (q < n_query_rows) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -504,7 +507,8 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __r
 
 namespace {
 int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
-                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_);
+                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_,
+                     int first_only = 0);
 }
 
 extern "C" int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
@@ -523,9 +527,21 @@ extern "C" int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_
                             d_out, stream_);
 }
 
+extern "C" int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
+                                                  int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                                  int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(d_cu_seqlens != nullptr || n_seq == 0, RAG_EINVAL, "rag_enc_attention_packed_first: null offsets");
+    RAG_REQUIRE(total_tokens >= 0 && total_tokens < (1ll << 31), RAG_ELIMIT,
+                "rag_enc_attention_packed_first: bad token count");
+    return attention_launch(d_qkv, nullptr, d_cu_seqlens, total_tokens, n_seq, max_seq_len, n_heads, head_dim, dtype,
+                            d_out, stream_, 1);
+}
+
 namespace {
 int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
-                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+                     int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_,
+                     int first_only) {
+    RAG_REQUIRE(!first_only || dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attention: first-token form is bf16 only");
     RAG_REQUIRE(n_seq >= 0 && seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention: bad sizes");
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_attention: unknown dtype");
     RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention: head_dim must be 32 or 64 (got %d)",
@@ -561,7 +577,7 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
             granted = 160 * 1024;
         }
         attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
-                                                            n_heads, scale, (bf16*)d_out, rag_fault_word());
+                                                            n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     } else {
         static size_t granted = 64 * 1024;
         if (lds > granted) {
@@ -570,7 +586,7 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
             granted = 160 * 1024;
         }
         attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
-                                                            n_heads, scale, (bf16*)d_out, rag_fault_word());
+                                                            n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     }
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;

@@ -145,10 +145,13 @@ class BertEncoder(nn.Module):
         return x
 
 
-    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len, first_token_only=False):
         """Unpadded batch on the GPU: ids/types/pos int32 [T], sequence i = tokens
-        [cu_seqlens[i], cu_seqlens[i+1]).  Returns hidden states [T, H].  Everything between
-        the GEMMs runs in librag_hip kernels (bfloat16 or float32 weights)."""
+        [cu_seqlens[i], cu_seqlens[i+1]).  Returns hidden states [T, H], or with
+        first_token_only (bfloat16) just the first token's row of every sequence [n_seq, H]:
+        the last layer then computes its output projection, feed-forward block and LayerNorms
+        for those rows only (identical values; a classifier head reads nothing else).
+        Everything between the GEMMs runs in librag_hip kernels (bfloat16 or float32 weights)."""
         import rag_hip
         c = self.config
         if not rag_hip.enc_attention_supported(self.word.weight.dtype, c.hidden_size // c.num_attention_heads,
@@ -159,7 +162,15 @@ class BertEncoder(nn.Module):
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else (lambda m, v: m(v))
-        for l in self.layers:
+        last = len(self.layers) - 1
+        for li, l in enumerate(self.layers):
+            if first_token_only and li == last and x.dtype == torch.bfloat16:
+                ctx = rag_hip.enc_attention_packed_first_dev(l.qkv(x), cu_seqlens, max_seq_len, l.heads)
+                x = x[cu_seqlens[:-1].long()]
+                x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias,
+                                                  l.attn_norm.eps)
+                return rag_hip.enc_add_layernorm_dev(l.ffn_out(F.gelu(l.ffn_in(x))), x, l.ffn_norm.weight,
+                                                     l.ffn_norm.bias, l.ffn_norm.eps)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
             x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                               l.attn_norm.eps)
@@ -221,8 +232,11 @@ class CrossEncoderModel(nn.Module):
 
     def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
         """Logits of an unpadded batch (every sequence non-empty, first token [CLS])."""
-        h = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)
-        logits = self.classifier(torch.tanh(self.pooler(h[cu_seqlens[:-1].long()])))
+        if self.bert.word.weight.dtype == torch.bfloat16:
+            cls = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True)
+        else:
+            cls = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)[cu_seqlens[:-1].long()]
+        logits = self.classifier(torch.tanh(self.pooler(cls)))
         return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
 
 

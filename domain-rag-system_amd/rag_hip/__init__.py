@@ -65,6 +65,7 @@ SIGNATURES = {
     'rag_ce_pair_len_dev': (_i32, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_dev': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
@@ -683,3 +684,17 @@ def split_weight_bf16x3(w):
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
     return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def enc_attention_packed_first_dev(qkv, cu_seqlens, max_seq_len, n_heads):
+    """Attention output of the first token of every sequence only: qkv [T, 3*H] bf16 ->
+    [n_seq, H] (rag_enc_attention_packed_first_dev)."""
+    import torch
+    t, h3 = qkv.shape
+    hidden = h3 // 3
+    n_seq = cu_seqlens.shape[0] - 1
+    out = torch.empty((n_seq, hidden), dtype=qkv.dtype, device=qkv.device)
+    check(lib().rag_enc_attention_packed_first_dev(_ptr(qkv, torch.bfloat16), _ptr(cu_seqlens, torch.int32), n_seq, t,
+                                                   int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
+                                                   _ptr(out), _stream()), 'rag_enc_attention_packed_first_dev')
+    return out

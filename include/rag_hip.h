@@ -261,6 +261,12 @@ int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_se
 int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
                                  int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
                                  int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* The packed form with only the FIRST token of every sequence as a query: out
+ * [n_seq][n_heads*head_dim].  A sequence classifier reads only the [CLS] row of the last
+ * layer, so that layer needs nothing else (bf16 only).                                  */
+int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
+                                       int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                       int32_t head_dim, int32_t dtype, void* d_out, void* stream);
 /* Sentence embedding of a packed fp32 batch: out[i] = mean of x over the tokens of
  * sequence i (the mean pooling over the attention mask of the sentence-transformers
  * pipeline behind reference src/indexing/embedder.py:65-71), L2-normalised when

@@ -249,3 +249,16 @@ def test_split_bf16_gemm_embedder_holds_the_cosine_tolerance():
     # the bar of the path: cosine scores within 1e-4 of the fp32 forward (here: 10x inside it)
     assert float(((a - p) @ corpus.t()).abs().max()) < 1e-5
     assert float((a - p).abs().max()) < 2e-5
+
+
+def test_first_token_attention_equals_row_zero_of_the_full_kernel():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(31)
+    lens = torch.randint(1, 140, (77,), generator=g, device=dev, dtype=torch.int32)
+    cu = torch.zeros((78,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    qkv = torch.randn((int(cu[-1]), 3 * 384), generator=g, device=dev).to(torch.bfloat16)
+    full = rag_hip.enc_attention_packed_dev(qkv, cu, int(lens.max()), 12)
+    first = rag_hip.enc_attention_packed_first_dev(qkv, cu, int(lens.max()), 12)
+    assert torch.equal(first, full[cu[:-1].long()])
