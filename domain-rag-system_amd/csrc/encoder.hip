@@ -55,8 +55,11 @@ constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes 
 // LDS image of one head's keys and values:
 //   K   [kpad][D + 8]     rows padded by 16 B: the 16-byte operand reads of 32 keys spread over the banks
 //   V^T [D][kpad + 4]     rows padded by 8 B: 32 lanes read 8 B of 32 different d rows without conflict
+#ifndef RAG_ATT_MIN_BLOCKS
+#define RAG_ATT_MIN_BLOCKS 6         // workgroups per CU the register budget is sized for
+#endif
 template <int D>
-__global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(const bf16* __restrict__ qkv,
                                                            const int32_t* __restrict__ lens,
                                                            const int32_t* __restrict__ cu, int64_t total_tokens,
                                                            int n_seq, int S_max, int NH, float scale,
@@ -105,23 +108,45 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
     bf16* Vt = Ks + (size_t)kpad * KROW;
 
     // ---- stage this head's keys (row-major) and values (transposed), zero beyond len
-    for (int idx = tid; idx < kpad * (D / 8); idx += ATT_NT) {
-        const int key = idx / (D / 8), c8 = idx - key * (D / 8);
-        bf16x8 kv, vv;
+    // Q^T fragments (B operand) of this wave's first query block: lane (h, r) holds Q[q][16c + 8h + j].
+    // Issued before the K/V staging so that both round trips to memory overlap.
+    const int n_query_rows = first_only ? 1 : S;
+    bf16x8 qf[KC];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
+        if (wave * 32 + r < S && wave * 32 < min(n_query_rows, len))
+            qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)(wave * 32 + r) * tok + head * D + 16 * c + 8 * h);
+    }
+    // each thread moves 8 dims of two neighbouring keys, so the transposed image is written 4 bytes at a time
+    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += ATT_NT) {
+        const int key = (idx / (D / 8)) * 2, c8 = idx % (D / 8);
+        bf16x8 k0, k1, v0, v1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { k0[j] = (bf16)0.f; k1[j] = (bf16)0.f; v0[j] = (bf16)0.f; v1[j] = (bf16)0.f; }
+        const bf16* p = base + (size_t)key * tok + head * D + c8 * 8;
         if (key < len) {
-            const bf16* p = base + (size_t)key * tok + head * D + c8 * 8;
-            kv = *reinterpret_cast<const bf16x8*>(p + H);
-            vv = *reinterpret_cast<const bf16x8*>(p + 2 * H);
+            k0 = *reinterpret_cast<const bf16x8*>(p + H);
+            v0 = *reinterpret_cast<const bf16x8*>(p + 2 * H);
         }
-        *reinterpret_cast<bf16x8*>(Ks + key * KROW + c8 * 8) = kv;
+        if (key + 1 < len) {
+            k1 = *reinterpret_cast<const bf16x8*>(p + tok + H);
+            v1 = *reinterpret_cast<const bf16x8*>(p + tok + 2 * H);
+        }
+        *reinterpret_cast<bf16x8*>(Ks + key * KROW + c8 * 8) = k0;
+        *reinterpret_cast<bf16x8*>(Ks + (key + 1) * KROW + c8 * 8) = k1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c8 * 8 + j) * VROW + key] = vv[j];
+        for (int j = 0; j < 8; ++j) {
+            bf16x2 pr;
+            pr[0] = v0[j];
+            pr[1] = v1[j];
+            *reinterpret_cast<bf16x2*>(Vt + (c8 * 8 + j) * VROW + key) = pr;
+        }
     }
     __syncthreads();
 
-    const int n_query_rows = first_only ? 1 : S;
     for (int qb = wave; qb * 32 < n_query_rows; qb += ATT_NT / 64) {
         const int q = qb * 32 + r;
         if (qb * 32 >= len) {
@@ -137,13 +162,13 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
             }
             continue;
         }
-        // Q^T fragments (B operand): lane (h, r) holds Q[q][16c + 8h + j]
-        bf16x8 qf[KC];
+        if (qb != wave) {                                // later blocks of a long sequence
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
+            for (int c = 0; c < KC; ++c) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
-            if (q < S) qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * tok + head * D + 16 * c + 8 * h);
+                for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
+                if (q < S) qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * tok + head * D + 16 * c + 8 * h);
+            }
         }
         float m_run = NEG_BIG, l_run = 0.f;
         f32x16 o[DT];
@@ -162,31 +187,43 @@ __global__ __launch_bounds__(ATT_NT) void attention_kernel(const bf16* __restric
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kb + r) * KROW + 16 * c + 8 * h);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[c], s, 0, 0, 0);
             }
+            // softmax in base 2: t = s * (scale * log2 e), p = 2^(t - m); only the last key block
+            // can hold keys beyond len
             float mx = NEG_BIG;
+            if (kb + 32 > len) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                s[i] = key < len ? s[i] * scale : NEG_BIG;
-                mx = fmaxf(mx, s[i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    s[i] = key < len ? s[i] * scale : NEG_BIG;
+                    mx = fmaxf(mx, s[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[i] *= scale;
+                    mx = fmaxf(mx, s[i]);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float p = key < len ? __expf(s[i] - m_new) : 0.f;
-                s[i] = p;
-                sum += p;
+                s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);      // masked keys: 2^(-1e30 - m) = 0
+                sum += s[i];
             }
             sum += __shfl_xor(sum, 32, 64);
-            l_run = l_run * alpha + sum;
+            if (kb > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run = l_run * alpha + sum;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            } else {
+                l_run = sum;
+            }
             m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
             // O^T += V^T P^T: the score registers 8t..8t+7 are the B fragment of k-step t; element j of
             // lane half h is key kb + 16t + 8(j>>2) + 4h + (j&3), so V^T is read in that order
 #pragma unroll
@@ -554,7 +591,7 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
     hipStream_t stream = (hipStream_t)stream_;
     const int kpad = (seq_len + 31) & ~31;
     const size_t lds = (size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2;
-    const float scale = 1.0f / sqrtf((float)head_dim);
+    const float scale = 1.4426950408889634f / sqrtf((float)head_dim);   // log2(e) / sqrt(D): the kernel works in base 2
     const unsigned grid = (unsigned)((int64_t)((n_seq + 7) / 8) * 8 * n_heads);
     if (dtype == RAG_DTYPE_F32) {
         const float scale32 = 1.0f / sqrtf((float)head_dim);
@@ -679,6 +716,33 @@ extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t 
     const int64_t n8 = rows * (k / 8);
     const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
     split_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (bf16*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+namespace {
+// Exact (erf) GELU, the activation of BERT's feed-forward block, elementwise and in place.
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(T* __restrict__ x, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float f[8];
+        Vec8<T>::load(x + i * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.5f * f[j] * (1.0f + erff(f[j] * 0.70710678118654752f));
+        Vec8<T>::store(x + i * 8, f);
+    }
+}
+}  // namespace
+
+extern "C" int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream_) {
+    RAG_REQUIRE(n >= 0 && n % 8 == 0, RAG_EINVAL, "rag_enc_gelu: element count must be a multiple of 8");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_gelu: unknown dtype");
+    if (n == 0) return RAG_OK;
+    RAG_REQUIRE(d_x != nullptr, RAG_EINVAL, "rag_enc_gelu: null pointer");
+    const int64_t n8 = n / 8;
+    const unsigned grid = (unsigned)(n8 / 256 + 1 > 256 * 64 ? 256 * 64 : n8 / 256 + 1);
+    if (dtype == RAG_DTYPE_BF16) gelu_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream_>>>((bf16*)d_x, n8);
+    else gelu_kernel<float><<<grid, 256, 0, (hipStream_t)stream_>>>((float*)d_x, n8);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

@@ -82,7 +82,7 @@ class BertLayer(nn.Module):
             ctx = rag_hip.enc_attention_dev(self.qkv(x), lens, self.heads)
             x = rag_hip.enc_add_layernorm_dev(self.attn_out(ctx), x, self.attn_norm.weight, self.attn_norm.bias,
                                               self.attn_norm.eps)
-            return rag_hip.enc_add_layernorm_dev(self.ffn_out(F.gelu(self.ffn_in(x))), x, self.ffn_norm.weight,
+            return rag_hip.enc_add_layernorm_dev(self.ffn_out(rag_hip.enc_gelu_(self.ffn_in(x))), x, self.ffn_norm.weight,
                                                  self.ffn_norm.bias, self.ffn_norm.eps)
         qkv = self.qkv(x).view(b, s, 3, self.heads, h // self.heads).permute(2, 0, 3, 1, 4)
         ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=attn_bias)
@@ -169,12 +169,12 @@ class BertEncoder(nn.Module):
                 x = x[cu_seqlens[:-1].long()]
                 x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                                   l.attn_norm.eps)
-                return rag_hip.enc_add_layernorm_dev(l.ffn_out(F.gelu(l.ffn_in(x))), x, l.ffn_norm.weight,
+                return rag_hip.enc_add_layernorm_dev(l.ffn_out(rag_hip.enc_gelu_(l.ffn_in(x))), x, l.ffn_norm.weight,
                                                      l.ffn_norm.bias, l.ffn_norm.eps)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
             x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                               l.attn_norm.eps)
-            x = rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, F.gelu(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
+            x = rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, rag_hip.enc_gelu_(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
                                               l.ffn_norm.bias, l.ffn_norm.eps)
         return x
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
+    'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
@@ -698,3 +699,9 @@ def enc_attention_packed_first_dev(qkv, cu_seqlens, max_seq_len, n_heads):
                                                    int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
                                                    _ptr(out), _stream()), 'rag_enc_attention_packed_first_dev')
     return out
+
+
+def enc_gelu_(x):
+    """In-place exact GELU (rag_enc_gelu_dev); returns x."""
+    check(lib().rag_enc_gelu_dev(_ptr(x), x.numel(), _enc_dtype(x), _stream()), 'rag_enc_gelu_dev')
+    return x

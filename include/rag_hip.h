@@ -274,6 +274,8 @@ int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_se
 int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq,
                           int64_t total_tokens, int32_t hidden, int32_t normalize, float* d_out,
                           void* stream);
+/* x := GELU(x) (exact erf form, BERT's "gelu"), in place over n elements (n % 8 == 0).  */
+int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
 /* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32
  * row x[r][0..k) becomes the bf16 row [hi | hi | lo] of 3k elements (hi = bf16(x),
  * lo = bf16(x - hi)).  Multiplied (fp32 accumulation) by weights laid out as

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Kernel-level timings of the encoder kernels at the cross-encoder's shapes (MiniLM-L6: hidden 384,
+12 heads of 32; pair lengths like the benchmark's: mean 73, max 157 tokens).
+
+    python scripts/encoder_bench.py [--tokens 1048576] [--iters 20]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'domain-rag-system_amd'))
+
+import numpy as np
+import torch
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tokens', type=int, default=1 << 20)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--hidden', type=int, default=384)
+    ap.add_argument('--heads', type=int, default=12)
+    args = ap.parse_args()
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(0)
+    lens = []
+    while sum(lens) < args.tokens - 160:
+        lens.append(int(np.clip(round(rng.lognormal(np.log(45), 0.6)), 2, 128)) + 2 + int(rng.integers(8, 25)) + 3)
+    lens.append(args.tokens - sum(lens))
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
+    cu = torch.zeros((len(lens) + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens_t, 0)
+    t, h = args.tokens, args.hidden
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn((t, 3 * h), generator=g, device=dev).to(torch.bfloat16)
+    x = torch.randn((t, h), generator=g, device=dev).to(torch.bfloat16)
+    res = torch.randn((t, h), generator=g, device=dev).to(torch.bfloat16)
+    gamma = torch.ones((h,), device=dev, dtype=torch.bfloat16)
+    beta = torch.zeros((h,), device=dev, dtype=torch.bfloat16)
+    longest = max(lens)
+    ms = timed(lambda: rag_hip.enc_attention_packed_dev(qkv, cu, longest, args.heads), args.iters)
+    gb = t * h * 2 * 4 / 1e9
+    print(f'attention: {len(lens)} sequences, {t} tokens: {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s of qkv+out traffic '
+          f'({gb:.2f} GB)', flush=True)
+    ms = timed(lambda: rag_hip.enc_add_layernorm_dev(x, res, gamma, beta, 1e-12), args.iters)
+    gb = t * h * 2 * 3 / 1e9
+    print(f'add+layernorm: {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s ({gb:.2f} GB)', flush=True)
+    ff = torch.randn((t, 4 * h), generator=g, device=dev).to(torch.bfloat16)
+    ms = timed(lambda: torch.nn.functional.gelu(ff), args.iters)
+    gb = t * 4 * h * 2 * 2 / 1e9
+    print(f'gelu (PyTorch): {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s ({gb:.2f} GB)', flush=True)
+    ms = timed(lambda: rag_hip.enc_gelu_(ff), args.iters)
+    print(f'gelu (in place): {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s ({gb:.2f} GB)', flush=True)
+    rag_hip.check_faults()
+
+
+if __name__ == '__main__':
+    main()

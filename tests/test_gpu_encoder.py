@@ -262,3 +262,16 @@ def test_first_token_attention_equals_row_zero_of_the_full_kernel():
     full = rag_hip.enc_attention_packed_dev(qkv, cu, int(lens.max()), 12)
     first = rag_hip.enc_attention_packed_first_dev(qkv, cu, int(lens.max()), 12)
     assert torch.equal(first, full[cu[:-1].long()])
+
+
+def test_gelu_in_place_matches_erf_gelu():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn((1000, 1536), generator=g, device=dev) * 3
+    ref = torch.nn.functional.gelu(x.double())
+    y = rag_hip.enc_gelu_(x.clone())
+    assert float((y.double() - ref).abs().max()) < 1e-6
+    xb = x.to(torch.bfloat16)
+    yb = rag_hip.enc_gelu_(xb.clone())
+    assert torch.equal(yb, torch.nn.functional.gelu(xb.float()).to(torch.bfloat16))
