@@ -52,6 +52,8 @@ def parse():
                     help='run the embedder on padded batches with PyTorch ops instead of the unpadded librag_hip path')
     ap.add_argument('--embed-fp32-gemm', action='store_true',
                     help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
+    ap.add_argument('--ce-fused-linear', action='store_true',
+                    help='cross-encoder output projection + residual + LayerNorm as one librag_hip GEMM')
     ap.add_argument('--ce-torch-ops', action='store_true',
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
@@ -245,6 +247,7 @@ def main():
     ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
     ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype,
                                native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
+    ce.bert.fused_linear = bool(args.ce_fused_linear)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
                              rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)

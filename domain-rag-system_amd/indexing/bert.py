@@ -103,6 +103,7 @@ class BertEncoder(nn.Module):
         self.native = False          # set by load_model(native=True): use the librag_hip encoder kernels
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
+        self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
 
     @staticmethod
     def pack(input_ids, attention_mask, token_type_ids=None):
@@ -172,8 +173,14 @@ class BertEncoder(nn.Module):
                 return rag_hip.enc_add_layernorm_dev(l.ffn_out(rag_hip.enc_gelu_(l.ffn_in(x))), x, l.ffn_norm.weight,
                                                      l.ffn_norm.bias, l.ffn_norm.eps)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
-            x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
-                                              l.attn_norm.eps)
+            if self.fused_linear and rag_hip.enc_linear_supported(ctx, l.attn_out.weight) and x.shape[1] == 384:
+                # output projection with bias + residual + LayerNorm in the GEMM epilogue
+                x = rag_hip.enc_linear_dev(ctx, l.attn_out.weight, l.attn_out.bias,
+                                           rag_hip.EPILOGUE_BIAS_RESIDUAL_LAYERNORM, x, l.attn_norm.weight,
+                                           l.attn_norm.bias, l.attn_norm.eps)
+            else:
+                x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
+                                                  l.attn_norm.eps)
             x = rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, rag_hip.enc_gelu_(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
                                               l.ffn_norm.bias, l.ffn_norm.eps)
         return x

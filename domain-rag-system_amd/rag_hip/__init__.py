@@ -68,6 +68,7 @@ SIGNATURES = {
     'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
+    'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
@@ -705,3 +706,31 @@ def enc_gelu_(x):
     """In-place exact GELU (rag_enc_gelu_dev); returns x."""
     check(lib().rag_enc_gelu_dev(_ptr(x), x.numel(), _enc_dtype(x), _stream()), 'rag_enc_gelu_dev')
     return x
+
+
+EPILOGUE_BIAS, EPILOGUE_BIAS_GELU, EPILOGUE_BIAS_RESIDUAL_LAYERNORM = 0, 1, 2
+
+
+def enc_linear_supported(x, weight):
+    import torch
+    return (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[1] % 64 == 0
+            and weight.shape[0] % 384 == 0)
+
+
+def enc_linear_dev(x, weight, bias, epilogue=EPILOGUE_BIAS, residual=None, gamma=None, beta=None, eps=1e-12):
+    """y = tail(x @ weight.T + bias) with the tail fused into the GEMM (rag_enc_linear_dev);
+    x [M, K] bf16, weight [N, K] bf16."""
+    import torch
+    m, k = x.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k or tuple(bias.shape) != (n,):
+        raise ValueError("weight must be [N, K] and bias [N]")
+    if epilogue == EPILOGUE_BIAS_RESIDUAL_LAYERNORM:
+        if residual is None or tuple(residual.shape) != (m, n) or tuple(gamma.shape) != (n,) or tuple(beta.shape) != (n,):
+            raise ValueError("the LayerNorm tail needs residual [M, N], gamma [N] and beta [N]")
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    bf = torch.bfloat16
+    check(lib().rag_enc_linear_dev(_ptr(x, bf), _ptr(weight, bf), _ptr(bias, bf), m, k, n, int(epilogue),
+                                   _ptr(residual, bf), _ptr(gamma, bf), _ptr(beta, bf), float(eps), DTYPE_BF16, _ptr(y),
+                                   _stream()), 'rag_enc_linear_dev')
+    return y

@@ -274,6 +274,19 @@ int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_se
 int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq,
                           int64_t total_tokens, int32_t hidden, int32_t normalize, float* d_out,
                           void* stream);
+/* Dense layer with its elementwise tail fused into the GEMM epilogue (bf16, fp32
+ * accumulation): y[m][n] = tail(sum_k x[m][k] w[n][k] + bias[n]), x [m][k], w [n][k] as
+ * nn.Linear stores it; k a multiple of 64, n a multiple of 384.  Tails:
+ *   RAG_EPILOGUE_BIAS                     y = v
+ *   RAG_EPILOGUE_BIAS_GELU                y = GELU(v)            (exact erf form)
+ *   RAG_EPILOGUE_BIAS_RESIDUAL_LAYERNORM  y = LayerNorm(v + residual[m]) * gamma + beta, n == 384
+ * y must not alias x; it may alias residual.                                            */
+#define RAG_EPILOGUE_BIAS 0
+#define RAG_EPILOGUE_BIAS_GELU 1
+#define RAG_EPILOGUE_BIAS_RESIDUAL_LAYERNORM 2
+int rag_enc_linear_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t k,
+                       int32_t n, int32_t epilogue, const void* d_residual, const void* d_gamma,
+                       const void* d_beta, float eps, int32_t dtype, void* d_y, void* stream);
 /* x := GELU(x) (exact erf form, BERT's "gelu"), in place over n elements (n % 8 == 0).  */
 int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
 /* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32
