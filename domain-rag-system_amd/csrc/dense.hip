@@ -125,9 +125,13 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
     const int64_t row_end = min(p.n_rows, row_begin + p.strip_rows);
     uint2* my_scratch = p.scratch + (size_t)blockIdx.x * BQ * p.cap;
 
+    // the running threshold starts from the best lower bound known for the query (-inf, or what a
+    // pre-pass over a sample of rows / other strips have published)
     for (int i = tid; i < BQ; i += NT) {
         cnt_s[i] = 0;
-        tau_s[i] = -INFINITY;
+        tau_s[i] = q0 + i < p.n_queries
+                       ? key_to_f32(__hip_atomic_load(&p.tau_shared[q0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                       : -INFINITY;
     }
     __syncthreads();
 
@@ -318,6 +322,15 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
         for (int i = lane; i < n; i += 64) dst[i] = src[i];
         if (lane == 0) p.cand_count[(size_t)q * p.n_strips + strip] = n;
     }
+}
+
+// Lower bound of every query's final K-th score from a finished top-K of SOME of the rows: if that
+// list is full, its last score is reached by K rows, so the final K-th score cannot be lower.
+__global__ void tau_from_topk_kernel(const float* __restrict__ score, const int32_t* __restrict__ count, int n_queries,
+                                     int k, uint32_t* __restrict__ tau) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    tau[q] = count[q] >= k ? f32_to_key(score[(size_t)q * k + k - 1]) : 0x007FFFFFu;   // else the key of -inf
 }
 
 // Exact score of chosen (query, row) pairs: one wave per pair.
@@ -512,7 +525,7 @@ extern "C" int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_
 namespace {
 
 template <int WQ, int TQ, int WR, int TR>
-int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
+int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool preset_tau = false) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
     p.n_qblocks = (p.n_queries + Cfg::BQ - 1) / Cfg::BQ;
     // one resident wave of workgroups (LDS decides how many fit a CU), strips a multiple of 8
@@ -537,7 +550,8 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
     if (rc) return rc;
     p.tau_shared = (uint32_t*)h->tau_shared.p;
     // key of -inf: below every real score
-    RAG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.tau_shared, 0x007FFFFF, (size_t)p.n_queries, stream));
+    if (!preset_tau)
+        RAG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.tau_shared, 0x007FFFFF, (size_t)p.n_queries, stream));
     p.scratch = (uint2*)h->scratch.p;
     p.cand = (uint2*)h->cand.p;
     p.cand_count = (int32_t*)h->cand_count.p;
@@ -549,14 +563,8 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream) {
                                         (int)Cfg::LDS_BYTES));
         attr_set[p.euclid] = true;
     }
-    const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING;
-    if (prof) RAG_HIP_TRY(hipEventRecord(h->ev0[h->prof_n], stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     RAG_HIP_TRY(hipGetLastError());
-    if (prof) {
-        RAG_HIP_TRY(hipEventRecord(h->ev1[h->prof_n], stream));
-        h->prof_n++;
-    }
     h->last_strips = p.n_strips;
     h->last_qblocks = p.n_qblocks;
     return RAG_OK;
@@ -600,15 +608,39 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     p.fault = rag_fault_word();
     if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
     int rc;
-    if (n_queries <= 32)
-        rc = launch_scan<1, 1, 4, 1>(h, p, stream);
-    else if (n_queries <= 64)
-        rc = launch_scan<1, 2, 4, 1>(h, p, stream);
-    else if (getenv("RAG_DENSE_WIDE") || n_queries < 256)
-        rc = launch_scan<2, 2, 2, 2>(h, p, stream);
-    else
-        rc = launch_scan<4, 2, 2, 2>(h, p, stream);
+    auto scan = [&](DenseScanParams& pp, bool preset) -> int {
+        if (n_queries <= 32) return launch_scan<1, 1, 4, 1>(h, pp, stream, preset);
+        if (n_queries <= 64) return launch_scan<1, 2, 4, 1>(h, pp, stream, preset);
+        if (getenv("RAG_DENSE_WIDE") || n_queries < 256) return launch_scan<2, 2, 2, 2>(h, pp, stream, preset);
+        return launch_scan<4, 2, 2, 2>(h, pp, stream, preset);
+    };
+    // Large batches over large shards: a pre-pass over the first rows (about 1.6 % of the scan)
+    // gives every query a threshold before the main pass starts, so the main pass appends and
+    // compacts candidates only for rows that beat the pre-pass's K-th score instead of letting
+    // each of its strips find a threshold from -inf on its own.  The result is the same exact
+    // top-K: the threshold is reached by K real rows.
+    const int64_t sample = ((int64_t)16384 > 64 * (int64_t)k ? 16384 : 64 * (int64_t)k + BN - 1) / BN * BN;
+    // timing aid: one event pair around everything the scan does (pre-pass included), not the final merge
+    const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING;
+    if (prof) RAG_HIP_TRY(hipEventRecord(h->ev0[h->prof_n], stream));
+    const bool prepass = n_queries >= 128 && h->n_rows >= 16 * sample && !getenv("RAG_DENSE_NO_PREPASS");
+    if (prepass) {
+        DenseScanParams p0 = p;
+        p0.n_rows = sample;
+        if ((rc = scan(p0, false))) return rc;
+        if ((rc = launch_merge_cand32(p0.cand, p0.cand_count, n_queries, p0.n_strips, k, k, h->row_base, d_out_score,
+                                      d_out_row, d_out_count, p.fault, stream)))
+            return rc;
+        tau_from_topk_kernel<<<(n_queries + 255) / 256, 256, 0, stream>>>(d_out_score, d_out_count, n_queries, k,
+                                                                          (uint32_t*)h->tau_shared.p);
+        RAG_HIP_TRY(hipGetLastError());
+    }
+    rc = scan(p, prepass);
     if (rc) return rc;
+    if (prof) {
+        RAG_HIP_TRY(hipEventRecord(h->ev1[h->prof_n], stream));
+        h->prof_n++;
+    }
     rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
                              d_out_row, d_out_count, p.fault, stream);
     if (rc) return rc;

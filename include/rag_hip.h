@@ -91,8 +91,9 @@ int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t met
 int rag_dense_destroy(rag_dense_t h);
 int64_t rag_dense_rows(rag_dense_t h);
 /* Measurement aid (no counterpart in the reference): while enabled, every search records a
- * HIP event pair around its scan kernel on the launch stream (up to 256 searches);
- * rag_dense_profile_read waits for them and returns the kernel durations in ms.      */
+ * HIP event pair on the launch stream around its scan (the threshold pre-pass over a sample
+ * of rows, when one runs, and the scan kernel; not the final merge), up to 256 searches;
+ * rag_dense_profile_read waits for them and returns the durations in ms.             */
 int rag_dense_profile(rag_dense_t h, int32_t enable);
 int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_n, int32_t* out_n);
 
