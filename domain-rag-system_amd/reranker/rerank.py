@@ -109,6 +109,17 @@ class CrossEncoderReranker(BaseReranker):
         if not pairs:
             return []
         enc = [self.encode_pair(a, b) for a, b in pairs]
+        if self.model.bert.native:
+            # one unpadded token stream (a query's pool is at most top_n pairs of <= max_length tokens)
+            import numpy as np
+            lens = np.array([len(e[0]) for e in enc], dtype=np.int64)
+            cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            dev = self.device
+            ids = torch.tensor([t for e in enc for t in e[0]], dtype=torch.int32, device=dev)
+            types = torch.tensor([t for e in enc for t in e[1]], dtype=torch.int32, device=dev)
+            pos = torch.from_numpy(np.concatenate([np.arange(l, dtype=np.int32) for l in lens])).to(dev)
+            logits = self.model.forward_packed(ids, types, pos, torch.from_numpy(cu).to(dev), int(lens.max()))
+            return [float(v) for v in logits.reshape(len(enc), -1)[:, 0].cpu().tolist()]
         order = sorted(range(len(enc)), key=lambda i: -len(enc[i][0]))
         out = [0.0] * len(enc)
         for s in range(0, len(enc), self.batch_size):

@@ -275,3 +275,30 @@ def test_gelu_in_place_matches_erf_gelu():
     xb = x.to(torch.bfloat16)
     yb = rag_hip.enc_gelu_(xb.clone())
     assert torch.equal(yb, torch.nn.functional.gelu(xb.float()).to(torch.bfloat16))
+
+
+def test_medical_embedder_packed_path_matches_padded_fp32():
+    from indexing.embedder import MedicalEmbedder
+    texts = ['aspirin side effects in adults', 'metformin', '', 'type 2 diabetes mellitus first line treatment options '
+             'and contraindications in chronic kidney disease ' * 3, 'warfarin inr monitoring'] * 7
+    fast = MedicalEmbedder('random:bert-base', device='cuda', tokens_per_batch=256)
+    assert fast.model.bert.native and fast.model.bert.split_gemm
+    plain = MedicalEmbedder('random:bert-base', device='cuda')
+    plain.model.bert.native = False
+    a, b = fast.encode(texts), plain.encode(texts)
+    assert a.shape == (len(texts), 768) and a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    assert float(np.abs(a - b).max()) < 2e-5
+    assert float(np.abs(np.linalg.norm(a, axis=1) - 1).max()) < 1e-5
+
+
+def test_cross_encoder_reranker_packed_path_matches_padded_fp32():
+    from reranker.rerank import CrossEncoderReranker
+    fast = CrossEncoderReranker('random:minilm-l6', device='cuda')
+    assert fast.model.bert.native
+    plain = CrossEncoderReranker('random:minilm-l6', device='cuda')
+    plain.model.bert.native = False
+    pairs = [('what treats hypertension', 'ace inhibitors lower blood pressure ' * k) for k in range(1, 30)]
+    pairs.append(('q', ''))
+    a, b = fast.score_pairs(pairs), plain.score_pairs(pairs)
+    assert len(a) == len(pairs)
+    assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4
