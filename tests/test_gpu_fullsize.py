@@ -1,4 +1,4 @@
-"""GPU: BASELINE.json's full sizes (1M x 768, 1M documents), checked through properties that
+"""GPU: the benchmark's full sizes (1M x 768, 1M documents), checked through properties that
 do not need the oracle to finish a brute-force pass per query: sortedness, exact re-scoring of
 the returned rows, self-retrieval, a threshold property against sampled rows, agreement of the
 BM25 top-k with a host sort of the kernel's own dense score vector, and bit-equality of that

@@ -63,7 +63,7 @@ def test_hybrid_indexer_matches_oracle_end_to_end(tmp_path):
 
 
 def test_scripts_1k_chunks_bm25_only(tmp_path):
-    """BASELINE configuration 1 on the real kernels: build with scripts/build_index.py, query
+    """The smallest benchmark configuration on the real kernels: build with scripts/build_index.py, query
     BM25-only top_k=5, ids and scores identical to the oracle."""
     sys.path.insert(0, os.path.join(ROOT, 'scripts'))
     import build_index

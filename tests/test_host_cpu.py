@@ -251,7 +251,7 @@ def test_rerankers_and_factory(backend):
 
 
 def test_scripts_build_and_query_1k_chunks_bm25_only(backend, tmp_path, capsys):
-    """BASELINE configuration 1: 1k synthetic chunks, BM25-only top_k=5 through the scripts."""
+    """The smallest benchmark configuration: 1k synthetic chunks, BM25-only top_k=5 through the scripts."""
     sys.path.insert(0, os.path.join(ROOT, 'scripts'))
     import build_index
     import query as query_script
