@@ -69,6 +69,7 @@ SIGNATURES = {
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
+    'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
@@ -709,6 +710,30 @@ def enc_gelu_(x):
 
 
 EPILOGUE_BIAS, EPILOGUE_BIAS_GELU, EPILOGUE_BIAS_RESIDUAL_LAYERNORM = 0, 1, 2
+
+
+def enc_mlp_supported(x, w1, w2):
+    import torch
+    return (x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+            and x.shape[-1] == 384 and w1.shape[1] == 384 and w1.shape[0] % 32 == 0)
+
+
+def enc_mlp_dev(x, w1, b1, w2, b2, gamma, beta, eps=1e-12):
+    """LayerNorm(x + GELU(x @ w1.T + b1) @ w2.T + b2) * gamma + beta in one kernel
+    (rag_enc_mlp_dev); x [M, 384] bf16, w1 [I, 384], w2 [384, I]."""
+    import torch
+    m, hid = x.shape
+    inter = w1.shape[0]
+    if tuple(w1.shape) != (inter, hid) or tuple(w2.shape) != (hid, inter) or tuple(b1.shape) != (inter,):
+        raise ValueError("w1 must be [I, H], w2 [H, I] and b1 [I]")
+    if tuple(b2.shape) != (hid,) or tuple(gamma.shape) != (hid,) or tuple(beta.shape) != (hid,):
+        raise ValueError("b2, gamma and beta must be [H]")
+    y = torch.empty_like(x)
+    bf = torch.bfloat16
+    check(lib().rag_enc_mlp_dev(_ptr(x, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma, bf),
+                                _ptr(beta, bf), float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()),
+          'rag_enc_mlp_dev')
+    return y
 
 
 def enc_linear_supported(x, weight):

@@ -288,6 +288,16 @@ int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t
 int rag_enc_linear_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t k,
                        int32_t n, int32_t epilogue, const void* d_residual, const void* d_gamma,
                        const void* d_beta, float eps, int32_t dtype, void* d_y, void* stream);
+/* Feed-forward block of a BERT layer in one kernel (bf16, fp32 accumulation):
+ *   y[m] = LayerNorm(x[m] + GELU(x[m] w1^T + b1) w2^T + b2) * gamma + beta
+ * x, y [m][hidden]; w1 [intermediate][hidden], w2 [hidden][intermediate] as nn.Linear stores
+ * them (the BertIntermediate / BertOutput sub-layers of the cross-encoder forward behind
+ * reference src/reranker/rerank.py:79-84).  The [m][intermediate] activation stays on chip.
+ * hidden == 384, intermediate a multiple of 32; y must not alias x.  GELU is the erf form,
+ * evaluated to 4e-5 absolute.                                                            */
+int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2,
+                    const void* d_b2, const void* d_gamma, const void* d_beta, float eps, int64_t m,
+                    int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y, void* stream);
 /* x := GELU(x) (exact erf form, BERT's "gelu"), in place over n elements (n % 8 == 0).  */
 int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
 /* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32

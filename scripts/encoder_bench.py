@@ -91,6 +91,22 @@ def main():
         fl = 2.0 * t * k * n
         print(f'{name}: K={k} N={n}: library+tail {ms_u:.3f} ms, fused {ms_f:.3f} ms '
               f'({fl / ms_f / 1e9:.0f} TFLOP/s)', flush=True)
+    # the whole feed-forward block: two library GEMMs + GELU + residual/LayerNorm kernels against one kernel
+    if h == 384:
+        l1 = torch.nn.Linear(h, 4 * h, device=dev, dtype=torch.bfloat16)
+        l2 = torch.nn.Linear(4 * h, h, device=dev, dtype=torch.bfloat16)
+
+        def mlp_unfused():
+            return rag_hip.enc_add_layernorm_dev(l2(rag_hip.enc_gelu_(l1(x))), x, gamma, beta, 1e-12)
+
+        def mlp_fused():
+            return rag_hip.enc_mlp_dev(x, l1.weight, l1.bias, l2.weight, l2.bias, gamma, beta, 1e-12)
+        with torch.no_grad():
+            ms_u = timed(mlp_unfused, args.iters)
+            ms_f = timed(mlp_fused, args.iters)
+        fl = 4.0 * t * h * 4 * h
+        print(f'feed-forward block: library GEMMs + tails {ms_u:.3f} ms, one kernel {ms_f:.3f} ms '
+              f'({fl / ms_f / 1e9:.0f} TFLOP/s)', flush=True)
     rag_hip.check_faults()
 
 
