@@ -42,14 +42,15 @@ constexpr int ML_HID = 384;                  // layer width
 constexpr int ML_BM = 128;                   // tokens per workgroup
 constexpr int ML_NT = 256;                   // four waves
 constexpr int ML_C = 32;                     // intermediate units per chunk
-constexpr int ML_LD1 = ML_HID + 8;           // W1 chunk row in LDS, elements (784 B)
-constexpr int ML_LD2 = ML_C + 8;             // W2 chunk row in LDS, elements (80 B)
 constexpr int ML_KS = ML_HID / 16;           // k-steps of the first product: 24
 constexpr int ML_YT = ML_HID / 32;           // accumulator tiles of Y^T: 12
-constexpr int ML_W1_PIECES = ML_C * (ML_HID / 8) / ML_NT;   // 16-byte pieces per thread and chunk: 6
-constexpr int ML_W2_PIECES = ML_HID * (ML_C / 8) / ML_NT;   // 6
-constexpr int ML_STAGE_ELEMS = ML_C * ML_LD1 + ML_HID * ML_LD2;
-constexpr size_t ML_LDS_BYTES = (size_t)2 * ML_STAGE_ELEMS * sizeof(bf16);
+constexpr int ML_W_BYTES = ML_C * ML_HID * 2;             // one W1 chunk = one W2 chunk = 24576 B
+constexpr int ML_W_DMAS = ML_W_BYTES / 1024 / (ML_NT / 64);   // 1-KiB direct-to-LDS loads per wave and chunk: 6
+constexpr int ML_PF = 4;                    // fragment reads in flight ahead of the MFMAs, in k-steps
+constexpr int ML_MAX_I = 8192;               // b1 sits in LDS
+// LDS image: W1 buffers [2][32 rows][48 x 16 B], W2 buffers [2][384 rows][4 x 16 B], b1 [I]
+constexpr int ML_OFF_W2 = 2 * ML_W_BYTES;
+constexpr int ML_OFF_B1 = 4 * ML_W_BYTES;
 
 struct MlpParams {
     const bf16* x;        // [M][384]
@@ -64,6 +65,16 @@ struct MlpParams {
     int I;
     float eps;
 };
+
+// One wave-instruction of a direct-to-LDS load: lane l's 16 bytes at gbase + voff land at LDS byte
+// lds_dst + 16 l (the destination is wave-uniform base + lane order; only the source is per lane).
+// M0 carries the destination and belongs to the compiler, so it is saved and restored inside the
+// statement.  The compiler does not count this load: wait with s_waitcnt vmcnt before reading.
+__device__ __forceinline__ void lds_dma16(uint32_t lds_dst, const void* gbase, uint32_t voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gbase) : "memory");
+}
 
 // GELU(v) = v/2 (1 + erf(v / sqrt 2)) for two values at a time (packed fp32 FMAs).  erf(z) is an odd
 // degree-17 polynomial fitted on |z| <= 3.2 and held constant beyond (erf(3.2) = 1 - 6e-6): absolute
@@ -90,13 +101,49 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
 
 __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16* const lds = reinterpret_cast<bf16*>(smem);          // [2] x { W1 chunk [32][392], W2 chunk [384][40] }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * ML_BM;
     const int64_t tok = m0 + wave * 32 + r;                   // this lane's token
     const int64_t tok_ld = min(tok, p.M - 1);                 // rows past M read the last row; never stored
     const int n_chunks = p.I / ML_C;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    // ---- weight staging, direct to LDS.  A wave-instruction fills 1 KiB of the image in lane order, so
+    // the image cannot be padded; bank conflicts are avoided by XOR-ing the 16-byte piece index with
+    // row bits instead, applied here on the source address and again where the fragments are read.
+    //   W1 image row q holds unit (q with bits 2 and 3 swapped) of the chunk: with that row order the
+    //   H^T accumulator registers 8t..8t+7 of a lane are units 16t + 8h + 0..7, the natural k order of
+    //   W2; piece j of the row sits at j ^ (q & 15).
+    //   W2 image row f (feature) holds the chunk's 32 units, piece j at j ^ ((f >> 2) & 3).
+    uint32_t off1[ML_W_DMAS], off2[ML_W_DMAS];                // per-lane source byte offsets inside a chunk
+#pragma unroll
+    for (int i = 0; i < ML_W_DMAS; ++i) {
+        const int L = 64 * (wave + 4 * i) + lane;             // piece index inside the image
+        const int q = L / 48, j1 = (L % 48) ^ (q & 15);
+        const int unit = (q & ~12) | ((q & 4) << 1) | ((q & 8) >> 1);
+        off1[i] = (uint32_t)((unit * ML_HID + j1 * 8) * 2);
+        const int f = L / 4, j2 = (L % 4) ^ ((f >> 2) & 3);
+        off2[i] = (uint32_t)((f * p.I + j2 * 8) * 2);
+    }
+    auto dma_w1 = [&](int c, int buf) {                      // chunk c of W1 -> W1 buffer buf
+        const bf16* g = p.w1 + (size_t)c * ML_C * ML_HID;
+#pragma unroll
+        for (int i = 0; i < ML_W_DMAS; ++i) lds_dma16(lds0 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), g, off1[i]);
+    };
+    auto dma_w2 = [&](int c, int buf) {
+        const bf16* g = p.w2 + c * ML_C;
+#pragma unroll
+        for (int i = 0; i < ML_W_DMAS; ++i)
+            lds_dma16(lds0 + ML_OFF_W2 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), g, off2[i]);
+    };
+    const int last = n_chunks - 1;
+    dma_w1(0, 0);
+    dma_w1(min(1, last), 1);
+    dma_w2(0, 0);
+    for (int i = tid; i < p.I / 8; i += ML_NT)
+        *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 16 * i) = *reinterpret_cast<const bf16x8*>(p.b1 + 8 * i);
 
     // ---- the wave's 32 rows of X as B fragments: lane (r, h) holds X[tok][16t + 8h .. + 7]
     bf16x8 xf[ML_KS];
@@ -106,42 +153,38 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
     }
 
-    // ---- weight staging: global -> registers one chunk ahead -> LDS
-    bf16x8 s1[ML_W1_PIECES], s2[ML_W2_PIECES];
-    bf16x4 b1n[4], b1c[4];
-    auto chunk_load = [&](int c) {
+    // ---- fragment addresses.  First product, k-step t: piece 2t + h of image row r, at
+    // 16 (t >> 3) + ((2 (t & 7) + h) ^ (r & 15)); second product, k-step t of tile m: piece 2t + h of
+    // image row 32 m + r.
+    const unsigned char* a1[8];
 #pragma unroll
-        for (int i = 0; i < ML_W1_PIECES; ++i) {
-            const int idx = tid + i * ML_NT, row = idx / (ML_HID / 8), pc = idx % (ML_HID / 8);
-            s1[i] = *reinterpret_cast<const bf16x8*>(p.w1 + (size_t)(c * ML_C + row) * ML_HID + pc * 8);
+    for (int u = 0; u < 8; ++u) a1[u] = smem + r * (ML_HID * 2) + 16 * ((2 * u + h) ^ (r & 15));
+    const unsigned char* a2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a2[t] = smem + ML_OFF_W2 + r * (ML_C * 2) + 16 * ((2 * t + h) ^ ((r >> 2) & 3));
+    const unsigned char* b1s = smem + ML_OFF_B1 + 16 * h;
+
+    auto bias_init = [&](int c, f32x16& acc) {               // registers 8t..8t+7 = units 16t + 8h + 0..7
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(b1s + c * (ML_C * 2) + 32 * t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[8 * t + j] = (float)b[j];
         }
-#pragma unroll
-        for (int i = 0; i < ML_W2_PIECES; ++i) {
-            const int idx = tid + i * ML_NT, feat = idx / (ML_C / 8), pc = idx % (ML_C / 8);
-            s2[i] = *reinterpret_cast<const bf16x8*>(p.w2 + (size_t)feat * p.I + c * ML_C + pc * 8);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b1n[q] = *reinterpret_cast<const bf16x4*>(p.b1 + c * ML_C + 8 * q + 4 * h);
     };
-    auto chunk_store = [&](int buf) {
-        bf16* w1s = lds + buf * ML_STAGE_ELEMS;
-        bf16* w2s = w1s + ML_C * ML_LD1;
+    auto gemm1 = [&](int buf, f32x16& acc) {
 #pragma unroll
-        for (int i = 0; i < ML_W1_PIECES; ++i) {
-            const int idx = tid + i * ML_NT, row = idx / (ML_HID / 8), pc = idx % (ML_HID / 8);
-            *reinterpret_cast<bf16x8*>(w1s + row * ML_LD1 + pc * 8) = s1[i];
+        for (int t = 0; t < ML_KS; ++t) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a1[t & 7] + buf * ML_W_BYTES + 256 * (t >> 3));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[t], acc, 0, 0, 0);
         }
+    };
+    auto gelu_pack = [&](const f32x16& acc, bf16x8* pf) {
 #pragma unroll
-        for (int i = 0; i < ML_W2_PIECES; ++i) {
-            const int idx = tid + i * ML_NT, feat = idx / (ML_C / 8), pc = idx % (ML_C / 8);
-            // units 8pc .. 8pc+7 of the chunk; inside a group of 16 units, unit 4a + b (a < 4, b < 4)
-            // goes to k position 8(a&1) + 4(a>>1) + b: the order in which the H^T accumulators hold them
-            const int g = pc >> 1, half = pc & 1;
-            bf16x4 lo, hi;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { lo[j] = s2[i][j]; hi[j] = s2[i][4 + j]; }
-            *reinterpret_cast<bf16x4*>(w2s + feat * ML_LD2 + 16 * g + 4 * half) = lo;
-            *reinterpret_cast<bf16x4*>(w2s + feat * ML_LD2 + 16 * g + 8 + 4 * half) = hi;
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 g = gelu2((f32x2){acc[i], acc[i + 1]});
+            pf[i >> 3][i & 7] = (bf16)g.x;
+            pf[i >> 3][(i & 7) + 1] = (bf16)g.y;
         }
     };
 
@@ -151,65 +194,65 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) yacc[m][i] = 0.f;
 
-    chunk_load(0);
-    chunk_store(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b1c[q] = b1n[q];
-    chunk_load(min(1, n_chunks - 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // ---- prologue: H^T of chunks 0 and 1; then W1 buffer 0 is free for chunk 2
+    f32x16 hraw, hacc;
+    bf16x8 pf[2];
+    bias_init(0, hacc);
+    gemm1(0, hacc);
+    bias_init(min(1, last), hraw);
+    gemm1(1, hraw);
+    __syncthreads();
+    dma_w1(min(2, last), 0);
+    gelu_pack(hacc, pf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- main loop, three chunks in flight: iteration c runs H^T of chunk c+2 (into hacc), the GELU
+    // of chunk c+1 (hraw -> pfn) and Y^T += W2 . H^T of chunk c (pf) — independent of one another, so
+    // the matrix unit, the vector ALU and the LDS reads overlap — while chunks c+3 of W1 and c+1 of W2
+    // stream into the buffers the previous iteration finished with.  Past the last chunk the loads
+    // and the first product repeat the last chunk (results unused): no branches in the loop body.
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
-        const bf16* w1s = lds + buf * ML_STAGE_ELEMS;
-        const bf16* w2s = w1s + ML_C * ML_LD1;
-
-        // chunk c+1 (in registers since the last iteration) goes to the other buffer, whose readers
-        // all passed the barrier that ended the last iteration; chunk c+2 takes the registers.  Past the
-        // last chunk the loads repeat it: no branch in the load stream.
-        chunk_store(buf ^ 1);
-        bf16x4 b1k[4];
+        dma_w1(min(c + 3, last), buf ^ 1);
+        dma_w2(min(c + 1, last), buf ^ 1);
+        bias_init(min(c + 2, last), hacc);
+        bf16x8 pfn[2];
+        const unsigned char* w2b0 = a2[0] + buf * ML_W_BYTES;
+        const unsigned char* w2b1 = a2[1] + buf * ML_W_BYTES;
+        // fragment reads run ML_PF steps ahead of the MFMAs that consume them
+        auto frag1 = [&](int s) {
+            return *reinterpret_cast<const bf16x8*>(a1[s & 7] + buf * ML_W_BYTES + 256 * (s >> 3));
+        };
+        auto frag2 = [&](int s) {
+            return *reinterpret_cast<const bf16x8*>((s / ML_YT ? w2b1 : w2b0) + (s % ML_YT) * (32 * ML_C * 2));
+        };
+        bf16x8 q1[ML_PF], q2[ML_PF];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b1k[q] = b1c[q];
+        for (int s = 0; s < ML_PF - 1; ++s) { q1[s] = frag1(s); q2[s] = frag2(s); }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b1c[q] = b1n[q];
-        chunk_load(min(c + 2, n_chunks - 1));
-
-        // ---- H^T = W1c . X^T: two accumulators (even / odd k-steps) so consecutive MFMAs are independent
-        f32x16 h0, h1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            h0[i] = (float)b1k[i >> 2][i & 3];                 // row (i&3) + 8(i>>2) + 4h of the chunk
-            h1[i] = 0.f;
-        }
-        {
-            const bf16* a = w1s + r * ML_LD1 + 8 * h;
-#pragma unroll
-            for (int t = 0; t < ML_KS; t += 2) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a + 16 * t);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a + 16 * t + 16);
-                h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xf[t], h0, 0, 0, 0);
-                h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xf[t + 1], h1, 0, 0, 0);
+        for (int s = 0; s < ML_KS; ++s) {
+            if (s + ML_PF - 1 < ML_KS) {
+                q1[(s + ML_PF - 1) % ML_PF] = frag1(s + ML_PF - 1);
+                q2[(s + ML_PF - 1) % ML_PF] = frag2(s + ML_PF - 1);
+            }
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1[s % ML_PF], xf[s], hacc, 0, 0, 0);
+            const int m = s % ML_YT, t = s / ML_YT;
+            yacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2[s % ML_PF], pf[t], yacc[m], 0, 0, 0);
+            if (s % 3 == 0) {
+                const int i = 2 * (s / 3);
+                const f32x2 g = gelu2((f32x2){hraw[i], hraw[i + 1]});
+                pfn[i >> 3][i & 7] = (bf16)g.x;
+                pfn[i >> 3][(i & 7) + 1] = (bf16)g.y;
             }
         }
-        // ---- GELU, then the accumulators become the B fragments of the second product
-        bf16x8 pf[2];
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const f32x2 g = gelu2((f32x2){h0[i] + h1[i], h0[i + 1] + h1[i + 1]});
-            pf[i >> 3][i & 7] = (bf16)g.x;
-            pf[i >> 3][(i & 7) + 1] = (bf16)g.y;
-        }
-        // ---- Y^T += W2c . H^T
-        {
-            const bf16* a = w2s + r * ML_LD2 + 8 * h;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int m = 0; m < ML_YT; ++m) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + m * 32 * ML_LD2 + 16 * t);
-                    yacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[t], yacc[m], 0, 0, 0);
-                }
-        }
+        pf[0] = pfn[0];
+        pf[1] = pfn[1];
+        hraw = hacc;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -261,24 +304,25 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
                                int32_t intermediate, int32_t dtype, void* d_y, void* stream_) {
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_mlp: bf16 only");
     RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
-    RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0, RAG_ELIMIT,
-                "rag_enc_mlp: intermediate size must be a multiple of %d (got %d)", ML_C, intermediate);
+    RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
+                "rag_enc_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I, intermediate);
     RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_mlp: negative row count");
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma && d_beta && d_y, RAG_EINVAL, "rag_enc_mlp: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_mlp: y must not alias x (x is read again as the residual)");
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_mlp: too many rows");
+    const size_t lds_bytes = (size_t)ML_OFF_B1 + 2 * (size_t)intermediate;
     static bool attr_set = false;
     if (!attr_set) {
         RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ML_LDS_BYTES));
+                                        ML_OFF_B1 + 2 * ML_MAX_I));
         attr_set = true;
     }
     MlpParams p;
     p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
     p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.y = (bf16*)d_y;
     p.M = m; p.I = intermediate; p.eps = eps;
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3((unsigned)ceil_div64(m, ML_BM)), dim3(ML_NT), ML_LDS_BYTES,
+    hipLaunchKernelGGL(mlp_fused_kernel, dim3((unsigned)ceil_div64(m, ML_BM)), dim3(ML_NT), lds_bytes,
                        (hipStream_t)stream_, p);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
