@@ -52,6 +52,8 @@ def parse():
                     help='run the embedder on padded batches with PyTorch ops instead of the unpadded librag_hip path')
     ap.add_argument('--embed-fp32-gemm', action='store_true',
                     help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
+    ap.add_argument('--ce-library-mlp', action='store_true',
+                    help='tuning aid: feed-forward blocks as library GEMMs + tail kernels instead of rag_enc_mlp_dev')
     ap.add_argument('--ce-fused-linear', action='store_true',
                     help='cross-encoder output projection + residual + LayerNorm as one librag_hip GEMM')
     ap.add_argument('--ce-torch-ops', action='store_true',
@@ -248,6 +250,7 @@ def main():
     ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype,
                                native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
     ce.bert.fused_linear = bool(args.ce_fused_linear)
+    ce.bert.fused_mlp = not args.ce_library_mlp
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
                              rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)

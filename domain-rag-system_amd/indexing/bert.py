@@ -104,6 +104,7 @@ class BertEncoder(nn.Module):
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
+        self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
 
     @staticmethod
     def pack(input_ids, attention_mask, token_type_ids=None):
@@ -170,8 +171,7 @@ class BertEncoder(nn.Module):
                 x = x[cu_seqlens[:-1].long()]
                 x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                                   l.attn_norm.eps)
-                return rag_hip.enc_add_layernorm_dev(l.ffn_out(rag_hip.enc_gelu_(l.ffn_in(x))), x, l.ffn_norm.weight,
-                                                     l.ffn_norm.bias, l.ffn_norm.eps)
+                return self._feed_forward(l, x, lin)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
             if self.fused_linear and rag_hip.enc_linear_supported(ctx, l.attn_out.weight) and x.shape[1] == 384:
                 # output projection with bias + residual + LayerNorm in the GEMM epilogue
@@ -181,9 +181,18 @@ class BertEncoder(nn.Module):
             else:
                 x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                                   l.attn_norm.eps)
-            x = rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, rag_hip.enc_gelu_(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
-                                              l.ffn_norm.bias, l.ffn_norm.eps)
+            x = self._feed_forward(l, x, lin)
         return x
+
+    def _feed_forward(self, l, x, lin):
+        """LayerNorm(x + W2 GELU(W1 x)): one kernel where rag_enc_mlp_dev covers the shape, else
+        library GEMMs with the GELU and residual+LayerNorm kernels between them."""
+        import rag_hip
+        if self.fused_mlp and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight):
+            return rag_hip.enc_mlp_dev(x.contiguous(), l.ffn_in.weight, l.ffn_in.bias, l.ffn_out.weight, l.ffn_out.bias,
+                                       l.ffn_norm.weight, l.ffn_norm.bias, l.ffn_norm.eps)
+        return rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, rag_hip.enc_gelu_(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
+                                             l.ffn_norm.bias, l.ffn_norm.eps)
 
     def _linear_split(self, module, x):
         """fp32 Linear on the bf16 matrix cores: three bf16 products accumulated in fp32 inside one
