@@ -15,13 +15,16 @@
 //   Y^T[feat][token] += W2 . H^T     B fragments = the accumulators of H^T, converted in place
 // A lane of a 32x32 accumulator tile holds one token (its column) and rows (i&3) + 8(i>>2) + 4h:
 // registers 8t..8t+7 are exactly the eight k values a lane must supply for k-step t of the next
-// product if that product's k order is permuted to match, and the permutation is applied to W2
-// while it is staged (no shuffles, no LDS round trip for H).  The intermediate dimension is walked
-// in chunks of 32 units: per chunk 24 MFMAs for H^T, the GELU on 16 registers, 24 MFMAs into the
-// twelve 32x32 tiles of Y^T (192 registers).  W1 / W2 chunks are double buffered in LDS (padded
-// rows: conflict-free 16-byte reads) and fetched from L2 one chunk ahead through registers.  The
-// epilogue adds bias and the residual (the block's own input), takes the LayerNorm statistics of a
-// token from the lane and its partner in the other half-wave, and stores bf16.
+// product if the rows of H^T are ordered to match, and that order is given to the W1 rows while
+// they are staged (no shuffles, no LDS round trip for H).  The intermediate dimension is walked in
+// chunks of 32 units: per chunk 24 MFMAs for H^T, the GELU on 16 registers, 24 MFMAs into the
+// twelve 32x32 tiles of Y^T (192 registers), with three chunks in flight (first product of chunk
+// c+2, GELU of c+1, second product of c).  W1 / W2 chunks are double buffered in LDS, filled by
+// direct-to-LDS loads from L2 (the images are XOR-swizzled, not padded: conflict-free 16-byte
+// reads); the fragment reads are issued from the source three k-steps ahead of their MFMAs.  The
+// epilogue adds bias and the residual (the block's own input, still in registers), takes the
+// LayerNorm statistics of a token from the lane and its partner in the other half-wave, and
+// stores bf16.
 //
 // Behind CrossEncoderReranker.score_pairs (reference src/reranker/rerank.py:79-84): the
 // intermediate / output sub-layers of the BertForSequenceClassification forward that
@@ -29,14 +32,28 @@
 #include "common.h"
 
 #include <math.h>
+#include <type_traits>
+#include <utility>
 
 namespace {
+
+#ifndef ML_STAMPS
+#define ML_STAMPS 0
+#endif
+#if ML_STAMPS
+__device__ unsigned long long ml_dbg[8];
+#define ML_STAMP(var) unsigned long long var = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define ML_STAMP(var)
+#endif
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ML_HID = 384;                  // layer width
 constexpr int ML_BM = 128;                   // tokens per workgroup
@@ -46,9 +63,10 @@ constexpr int ML_KS = ML_HID / 16;           // k-steps of the first product: 24
 constexpr int ML_YT = ML_HID / 32;           // accumulator tiles of Y^T: 12
 constexpr int ML_W_BYTES = ML_C * ML_HID * 2;             // one W1 chunk = one W2 chunk = 24576 B
 constexpr int ML_W_DMAS = ML_W_BYTES / 1024 / (ML_NT / 64);   // 1-KiB direct-to-LDS loads per wave and chunk: 6
-constexpr int ML_PF = 4;                    // fragment reads in flight ahead of the MFMAs, in k-steps
+constexpr int ML_PF = 3;                    // fragment reads run this many k-steps ahead of their MFMAs
 constexpr int ML_MAX_I = 8192;               // b1 sits in LDS
-// LDS image: W1 buffers [2][32 rows][48 x 16 B], W2 buffers [2][384 rows][4 x 16 B], b1 [I]
+// LDS image: W1 buffers [2][32 rows][48 x 16 B], W2 buffers [2][384 rows][4 x 16 B], b1 [I] as fp32,
+// then b2, gamma, beta [384] as bf16
 constexpr int ML_OFF_W2 = 2 * ML_W_BYTES;
 constexpr int ML_OFF_B1 = 4 * ML_W_BYTES;
 
@@ -76,31 +94,60 @@ __device__ __forceinline__ void lds_dma16(uint32_t lds_dst, const void* gbase, u
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gbase) : "memory");
 }
 
-// GELU(v) = v/2 (1 + erf(v / sqrt 2)) for two values at a time (packed fp32 FMAs).  erf(z) is an odd
-// degree-17 polynomial fitted on |z| <= 3.2 and held constant beyond (erf(3.2) = 1 - 6e-6): absolute
-// error of the GELU below 4e-5, a fiftieth of the bf16 rounding of values near 1 — and no
+// LDS reads whose completion the SOURCE waits for, so that they can run several MFMAs ahead of their use
+// (the compiler issues a fragment read right before the MFMA that needs it and waits for it there).
+// lds_read16 only issues; the value is defined after an lds_wait<N> that names the register, with
+// N = the number of LDS reads issued after it (LDS reads complete in order).
+template <int OFF, typename T>
+__device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
+    static_assert(2 * ML_W_DMAS <= ML_KS, "one weight load per k-step");
+    static_assert(sizeof(T) == 16 && OFF >= 0 && OFF < 65536, "16-byte read, 16-bit offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N, typename T>
+__device__ __forceinline__ void lds_wait(T& a, T& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int... Is, typename F>
+__device__ __forceinline__ void unrolled(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// GELU(v) = v Phi(v), Phi(v) = (1 + erf(v / sqrt 2)) / 2, for two values at a time.  Phi(v) - 1/2 is an
+// odd degree-17 polynomial in v fitted on |v| <= 4.525 and held constant beyond (Phi(4.525) = 1 - 3e-6):
+// absolute error of the GELU below 6e-5, a fiftieth of the bf16 rounding of values near 1 — and no
 // exponential or reciprocal, which run at a quarter of the FMA rate.
+// The same evaluation in three slices (head: clamp, square, three FMAs; mid: four FMAs; tail: the rest).
+#define ML_K2(x) ((f32x2){x, x})
+__device__ __forceinline__ void gelu_head(f32x2 v, f32x2& c, f32x2& s, f32x2& p) {
+    c.x = __builtin_amdgcn_fmed3f(v.x, -4.525483400f, 4.525483400f);
+    c.y = __builtin_amdgcn_fmed3f(v.y, -4.525483400f, 4.525483400f);
+    s = c * c;
+    p = __builtin_elementwise_fma(ML_K2(2.882145399e-11f), s, ML_K2(-3.184668485e-09f));
+    p = __builtin_elementwise_fma(p, s, ML_K2(1.545971132e-07f));
+    p = __builtin_elementwise_fma(p, s, ML_K2(-4.369227442e-06f));
+}
+__device__ __forceinline__ void gelu_mid(f32x2 s, f32x2& p) {
+    p = __builtin_elementwise_fma(p, s, ML_K2(8.056942605e-05f));
+    p = __builtin_elementwise_fma(p, s, ML_K2(-1.032623707e-03f));
+    p = __builtin_elementwise_fma(p, s, ML_K2(9.570434947e-03f));
+    p = __builtin_elementwise_fma(p, s, ML_K2(-6.596714181e-02f));
+}
+__device__ __forceinline__ f32x2 gelu_tail(f32x2 v, f32x2 c, f32x2 s, f32x2 p) {
+    p = __builtin_elementwise_fma(p, s, ML_K2(3.987103009e-01f));
+    const f32x2 phi = __builtin_elementwise_fma(p, c, ML_K2(0.5f));
+    return v * phi;
+}
 __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
-    f32x2 z = v * 0.70710678118654752f;
-    z.x = fminf(fmaxf(z.x, -3.2f), 3.2f);
-    z.y = fminf(fmaxf(z.y, -3.2f), 3.2f);
-    const f32x2 s = z * z;
-    f32x2 p = {2.086896185e-08f, 2.086896185e-08f};
-    p = __builtin_elementwise_fma(p, s, (f32x2){-1.152973149e-06f, -1.152973149e-06f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){2.798506678e-05f, 2.798506678e-05f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){-3.954573252e-04f, -3.954573252e-04f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){3.646156001e-03f, 3.646156001e-03f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){-2.336560723e-02f, -2.336560723e-02f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){1.082771112e-01f, 1.082771112e-01f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){-3.731665065e-01f, -3.731665065e-01f});
-    p = __builtin_elementwise_fma(p, s, (f32x2){1.127723030e+00f, 1.127723030e+00f});
-    const f32x2 e = p * z;                                    // erf(v / sqrt 2)
-    const f32x2 hv = v * 0.5f;
-    return __builtin_elementwise_fma(hv, e, hv);
+    f32x2 c, s, p;
+    gelu_head(v, c, s, p);
+    gelu_mid(s, p);
+    return gelu_tail(v, c, s, p);
 }
 
 __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ML_STAMP(tk0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -142,8 +189,13 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     dma_w1(0, 0);
     dma_w1(min(1, last), 1);
     dma_w2(0, 0);
-    for (int i = tid; i < p.I / 8; i += ML_NT)
-        *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 16 * i) = *reinterpret_cast<const bf16x8*>(p.b1 + 8 * i);
+    for (int i = tid; i < p.I; i += ML_NT) *reinterpret_cast<float*>(smem + ML_OFF_B1 + 4 * i) = (float)p.b1[i];
+    if (tid < 3 * (ML_HID / 8)) {                           // b2 | gamma | beta behind b1, bf16
+        const int vsel = tid / (ML_HID / 8), piece = tid % (ML_HID / 8);
+        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : p.beta;
+        *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (vsel * ML_HID + piece * 8)) =
+            *reinterpret_cast<const bf16x8*>(src + piece * 8);
+    }
 
     // ---- the wave's 32 rows of X as B fragments: lane (r, h) holds X[tok][16t + 8h .. + 7]
     bf16x8 xf[ML_KS];
@@ -162,27 +214,28 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     const unsigned char* a2[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) a2[t] = smem + ML_OFF_W2 + r * (ML_C * 2) + 16 * ((2 * t + h) ^ ((r >> 2) & 3));
-    const unsigned char* b1s = smem + ML_OFF_B1 + 16 * h;
+    // registers 8t..8t+7 of an H^T accumulator are units 16t + 8h + 0..7 of its chunk
+    const unsigned char* b1s = smem + ML_OFF_B1 + 32 * h;
+    const uint32_t l1[8] = {(uint32_t)(uintptr_t)a1[0], (uint32_t)(uintptr_t)a1[1], (uint32_t)(uintptr_t)a1[2],
+                            (uint32_t)(uintptr_t)a1[3], (uint32_t)(uintptr_t)a1[4], (uint32_t)(uintptr_t)a1[5],
+                            (uint32_t)(uintptr_t)a1[6], (uint32_t)(uintptr_t)a1[7]};
+    const uint32_t l2[2] = {(uint32_t)(uintptr_t)a2[0], (uint32_t)(uintptr_t)a2[1]};
+    const uint32_t lb = (uint32_t)(uintptr_t)b1s;
 
-    auto bias_init = [&](int c, f32x16& acc) {               // registers 8t..8t+7 = units 16t + 8h + 0..7
+    auto gemm1 = [&](int buf, f32x16& acc) {                  // prologue only: compiler-scheduled reads
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(b1s + c * (ML_C * 2) + 32 * t);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[8 * t + j] = (float)b[j];
-        }
-    };
-    auto gemm1 = [&](int buf, f32x16& acc) {
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(a1[t & 7] + buf * ML_W_BYTES + 256 * (t >> 3));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[t], acc, 0, 0, 0);
         }
     };
-    auto gelu_pack = [&](const f32x16& acc, bf16x8* pf) {
+    auto gelu_pack = [&](int c, const f32x16& acc, bf16x8* pf) {
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-            const f32x2 g = gelu2((f32x2){acc[i], acc[i + 1]});
+            const f32x2 b = *reinterpret_cast<const f32x2*>(b1s + c * (ML_C * 4) + 64 * (i >> 3) + 4 * (i & 7));
+            const f32x2 g = gelu2((f32x2){acc[i], acc[i + 1]} + b);
             pf[i >> 3][i & 7] = (bf16)g.x;
             pf[i >> 3][(i & 7) + 1] = (bf16)g.y;
         }
@@ -198,81 +251,146 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     __syncthreads();
 
     // ---- prologue: H^T of chunks 0 and 1; then W1 buffer 0 is free for chunk 2
-    f32x16 hraw, hacc;
-    bf16x8 pf[2];
-    bias_init(0, hacc);
-    gemm1(0, hacc);
-    bias_init(min(1, last), hraw);
-    gemm1(1, hraw);
+    f32x16 hA, hB;
+    bf16x8 pA[2], pB[2];
+    gemm1(0, hA);
+    gemm1(1, hB);
     __syncthreads();
     dma_w1(min(2, last), 0);
-    gelu_pack(hacc, pf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gelu_pack(0, hA, pA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- main loop, three chunks in flight: iteration c runs H^T of chunk c+2 (into hacc), the GELU
-    // of chunk c+1 (hraw -> pfn) and Y^T += W2 . H^T of chunk c (pf) — independent of one another, so
-    // the matrix unit, the vector ALU and the LDS reads overlap — while chunks c+3 of W1 and c+1 of W2
-    // stream into the buffers the previous iteration finished with.  Past the last chunk the loads
-    // and the first product repeat the last chunk (results unused): no branches in the loop body.
-    for (int c = 0; c < n_chunks; ++c) {
-        const int buf = c & 1;
-        dma_w1(min(c + 3, last), buf ^ 1);
-        dma_w2(min(c + 1, last), buf ^ 1);
-        bias_init(min(c + 2, last), hacc);
-        bf16x8 pfn[2];
-        const unsigned char* w2b0 = a2[0] + buf * ML_W_BYTES;
-        const unsigned char* w2b1 = a2[1] + buf * ML_W_BYTES;
-        // fragment reads run ML_PF steps ahead of the MFMAs that consume them
-        auto frag1 = [&](int s) {
-            return *reinterpret_cast<const bf16x8*>(a1[s & 7] + buf * ML_W_BYTES + 256 * (s >> 3));
+    // ---- main loop, three chunks in flight: iteration c runs H^T of chunk c+2 (into hnew), the GELU
+    // of chunk c+1 (hold -> pnext) and Y^T += W2 . H^T of chunk c (pcur) — independent of one another,
+    // so the matrix unit, the vector ALU and the LDS reads overlap — while chunks c+3 of W1 and c+1 of
+    // W2 stream into the buffers the previous iteration finished with.  Past the last chunk the loads
+    // and the first product repeat the last chunk (results unused): no branches in the body.  Two
+    // iterations are written out with the roles of the accumulators swapped and the buffer index a
+    // constant, so every fragment address is a fixed register plus an immediate.
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if ML_STAMPS
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+#endif
+    auto iteration = [&](int c, auto buf_c, f32x16& hnew, const f32x16& hold, const bf16x8* pcur, bf16x8* pnext) {
+        constexpr int BUF = decltype(buf_c)::value;
+        ML_STAMP(t0);
+        // the weight loads are issued one per k-step over the first half of the steps, between MFMAs
+        // (issuing one costs the wave some 50 cycles, which the matrix unit covers there and would not
+        // cover in one block up front; the second half of the steps gives the last ones time to land)
+        const bf16* g1 = p.w1 + (size_t)min(c + 3, last) * ML_C * ML_HID;
+        const bf16* g2 = p.w2 + min(c + 1, last) * ML_C;
+        ML_STAMP(t1);
+        // bias of chunk c+1 (for the GELU), then the fragment ring: k-step s uses slot s % (ML_PF + 1)
+        f32x4 bias[4];
+        const uint32_t lbc = lb + (uint32_t)min(c + 1, last) * (ML_C * 4);
+        lds_read16<0>(bias[0], lbc);
+        lds_read16<16>(bias[1], lbc);
+        lds_read16<64>(bias[2], lbc);
+        lds_read16<80>(bias[3], lbc);
+        u32x4 q1[ML_PF + 1], q2[ML_PF + 1];
+        f32x2 gv, gc, gs, gp;
+        auto issue = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q1[S % (ML_PF + 1)], l1[S & 7]);
+            lds_read16<BUF * ML_W_BYTES + (S % ML_YT) * (32 * ML_C * 2)>(q2[S % (ML_PF + 1)], l2[S / ML_YT]);
         };
-        auto frag2 = [&](int s) {
-            return *reinterpret_cast<const bf16x8*>((s / ML_YT ? w2b1 : w2b0) + (s % ML_YT) * (32 * ML_C * 2));
+        auto step = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (S < 2 * ML_W_DMAS) {
+                constexpr int G = S;
+                if constexpr (G < ML_W_DMAS)
+                    lds_dma16(lds0 + (BUF ^ 1) * ML_W_BYTES + 1024 * (wave + 4 * G), g1, off1[G]);
+                else
+                    lds_dma16(lds0 + ML_OFF_W2 + (BUF ^ 1) * ML_W_BYTES + 1024 * (wave + 4 * (G - ML_W_DMAS)), g2,
+                              off2[G - ML_W_DMAS]);
+            }
+            if constexpr (S + ML_PF < ML_KS) issue(std::integral_constant<int, S + ML_PF>{});
+            constexpr int newer = 2 * (ML_KS - 1 - S < ML_PF ? ML_KS - 1 - S : ML_PF);   // reads issued after this step's
+            lds_wait<newer>(q1[S % (ML_PF + 1)], q2[S % (ML_PF + 1)]);
+            if constexpr (S == 0)
+                hnew = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q1[0]), xf[0], zero16, 0, 0, 0);
+            else
+                hnew = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q1[S % (ML_PF + 1)]), xf[S], hnew, 0, 0, 0);
+            constexpr int M = S % ML_YT, T = S / ML_YT;
+            yacc[M] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q2[S % (ML_PF + 1)]), pcur[T], yacc[M], 0, 0, 0);
+            // the GELU of one register pair is spread over three k-steps, each slice pinned behind this
+            // step's MFMAs (the empty asm statements keep their place among the LDS statements), so the
+            // vector work issues while the matrix unit is busy instead of in one block.  (Pinning the
+            // MFMAs themselves the same way costs more than it gains: the compiler then pads each with
+            // the wait states of a reader of its result.)
+            constexpr int I = 2 * (S / 3);                     // registers I, I+1 of the accumulator
+            if constexpr (S % 3 == 0) {
+                const f32x4 b4 = bias[I >> 2];
+                const f32x2 b = (I & 2) ? (f32x2){b4[2], b4[3]} : (f32x2){b4[0], b4[1]};
+                gv = (f32x2){hold[I], hold[I + 1]} + b;
+                gelu_head(gv, gc, gs, gp);
+                asm volatile("" : "+v"(gp), "+v"(gs));
+            } else if constexpr (S % 3 == 1) {
+                gelu_mid(gs, gp);
+                asm volatile("" : "+v"(gp));
+            } else {
+                f32x2 g = gelu_tail(gv, gc, gs, gp);
+                asm volatile("" : "+v"(g));
+                pnext[I >> 3][I & 7] = (bf16)g.x;
+                pnext[I >> 3][(I & 7) + 1] = (bf16)g.y;
+            }
         };
-        bf16x8 q1[ML_PF], q2[ML_PF];
-#pragma unroll
-        for (int s = 0; s < ML_PF - 1; ++s) { q1[s] = frag1(s); q2[s] = frag2(s); }
-#pragma unroll
-        for (int s = 0; s < ML_KS; ++s) {
-            if (s + ML_PF - 1 < ML_KS) {
-                q1[(s + ML_PF - 1) % ML_PF] = frag1(s + ML_PF - 1);
-                q2[(s + ML_PF - 1) % ML_PF] = frag2(s + ML_PF - 1);
-            }
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1[s % ML_PF], xf[s], hacc, 0, 0, 0);
-            const int m = s % ML_YT, t = s / ML_YT;
-            yacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2[s % ML_PF], pf[t], yacc[m], 0, 0, 0);
-            if (s % 3 == 0) {
-                const int i = 2 * (s / 3);
-                const f32x2 g = gelu2((f32x2){hraw[i], hraw[i + 1]});
-                pfn[i >> 3][i & 7] = (bf16)g.x;
-                pfn[i >> 3][(i & 7) + 1] = (bf16)g.y;
-            }
-        }
-        pf[0] = pfn[0];
-        pf[1] = pfn[1];
-        hraw = hacc;
+        unrolled(std::make_integer_sequence<int, ML_PF>{}, issue);
+        // the bias reads were issued before the first 2 ML_PF fragment reads
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) : "n"(2 * ML_PF));
+        unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
+        ML_STAMP(t2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ML_STAMP(t3);
         __syncthreads();
+        ML_STAMP(t4);
+#if ML_STAMPS
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += t4 - t3; st[4] += 1;
+#endif
+    };
+#if ML_STAMPS
+    ML_STAMP(tl0);
+#endif
+    for (int c = 0; c < n_chunks; c += 2) {
+        iteration(c, std::integral_constant<int, 0>{}, hA, hB, pA, pB);
+        if (c + 1 < n_chunks) iteration(c + 1, std::integral_constant<int, 1>{}, hB, hA, pB, pA);
     }
 
-    // ---- epilogue: yacc[m][i] is feature 32m + (i&3) + 8(i>>2) + 4h of token `tok`
-    const bf16* xres = p.x + tok_ld * ML_HID;
+#if ML_STAMPS
+    ML_STAMP(tl1);
+    const unsigned long long tpro = tl0 - tk0;
+#endif
+    // ---- epilogue: yacc[m][i] is feature 32m + (i&3) + 8(i>>2) + 4h of token `tok`.  The residual is
+    // the block's own input, still in xf: lane (r, h) holds columns 16t + 8h + 0..7 of its token and needs
+    // columns 8q' + 4h + 0..3 for every q' — half of them are its own, the other half sit in the partner
+    // lane of the other half-wave (one exchange of two registers per k-step, no second trip to memory).
+    // b2, gamma and beta come from LDS.
+    const unsigned char* vecs = smem + ML_OFF_B1 + 4 * (size_t)p.I + 8 * h;
+    auto bf2f = [](uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); };
     float sum = 0.f;
 #pragma unroll
-    for (int m = 0; m < ML_YT; ++m)
+    for (int t = 0; t < ML_KS; ++t) {
+        const u32x4 d = __builtin_bit_cast(u32x4, xf[t]);
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)(h ? d[0] : d[2]), 32, 64);
+        const uint32_t r1 = (uint32_t)__shfl_xor((int)(h ? d[1] : d[3]), 32, 64);
+        const uint32_t w[2][2] = {{h ? r0 : d[0], h ? r1 : d[1]}, {h ? d[2] : r0, h ? d[3] : r1}};
+        const int m = t >> 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = 32 * m + 8 * q + 4 * h;
-            const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.b2 + n);
-            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(xres + n);
+        for (int k = 0; k < 2; ++k) {
+            const int q = 2 * (t & 1) + k;
+            const bf16x4 bb = *reinterpret_cast<const bf16x4*>(vecs + 2 * (32 * m + 8 * q));
+            float rr[4];
+            bf2f(w[k][0], rr[0], rr[1]);
+            bf2f(w[k][1], rr[2], rr[3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v = yacc[m][4 * q + j] + (float)bb[j] + (float)rr[j];
+                const float v = yacc[m][4 * q + j] + (float)bb[j] + rr[j];
                 yacc[m][4 * q + j] = v;
                 sum += v;
             }
         }
+    }
     sum += __shfl_xor(sum, 32, 64);
     const float mean = sum / (float)ML_HID;
     float sq = 0.f;
@@ -287,17 +405,30 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     for (int m = 0; m < ML_YT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = 32 * m + 8 * q + 4 * h;
-            const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(p.gamma + n);
-            const bf16x4 be4 = *reinterpret_cast<const bf16x4*>(p.beta + n);
+            const int n = 32 * m + 8 * q;
+            const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(vecs + 2 * (ML_HID + n));
+            const bf16x4 be4 = *reinterpret_cast<const bf16x4*>(vecs + 2 * (2 * ML_HID + n));
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (bf16)((yacc[m][4 * q + j] - mean) * rstd * (float)g4[j] + (float)be4[j]);
-            if (live) *reinterpret_cast<bf16x4*>(p.y + tok * ML_HID + n) = o;
+            if (live) *reinterpret_cast<bf16x4*>(p.y + tok * ML_HID + n + 4 * h) = o;
         }
+#if ML_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ML_STAMP(tk1);
+    if (blockIdx.x == 300 && tid == 64) { for (int i = 0; i < 5; ++i) ml_dbg[i] = st[i]; ml_dbg[5] = tl1 - tl0; ml_dbg[6] = tpro; ml_dbg[7] = tk1 - tl1; }
+#endif
 }
 
 }  // namespace
+
+#if ML_STAMPS
+extern "C" int rag_enc_mlp_debug(unsigned long long* out8) {
+    RAG_HIP_TRY(hipDeviceSynchronize());
+    RAG_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ml_dbg), 8 * sizeof(unsigned long long)));
+    return RAG_OK;
+}
+#endif
 
 extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                                const void* d_gamma, const void* d_beta, float eps, int64_t m, int32_t hidden,
@@ -311,11 +442,11 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
     RAG_REQUIRE(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma && d_beta && d_y, RAG_EINVAL, "rag_enc_mlp: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_mlp: y must not alias x (x is read again as the residual)");
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_mlp: too many rows");
-    const size_t lds_bytes = (size_t)ML_OFF_B1 + 2 * (size_t)intermediate;
+    const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)intermediate + 3 * ML_HID * 2;
     static bool attr_set = false;
     if (!attr_set) {
         RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ML_OFF_B1 + 2 * ML_MAX_I));
+                                        ML_OFF_B1 + 4 * ML_MAX_I + 3 * ML_HID * 2));
         attr_set = true;
     }
     MlpParams p;
