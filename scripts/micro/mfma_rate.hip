@@ -1,4 +1,6 @@
-// Issue-rate probe: independent v_mfma_f32_32x32x16_bf16 streams with 1, 2 or 4 waves per SIMD.
+// Issue-rate probe: v_mfma_f32_32x32x16_bf16 streams with 1, 2 or 4 waves per SIMD and 4 accumulators per
+// wave (an MFMA that continues an accumulator four MFMAs after the one that wrote it runs at full
+// rate: 2.0-2.1 PFLOP/s with one wave per SIMD; at distance two the rate halves).
 // Build: hipcc -O3 --offload-arch=gfx950 mfma_rate.hip -o mfma_rate ; run: ./mfma_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -43,7 +45,7 @@ void run(int waves_per_simd, float seed) {
 
 int main() {
     for (float seed : {0.f, 1.37f}) {
-        run<4>(1, seed); run<12>(1, seed); run<4>(2, seed); run<12>(2, seed); run<4>(4, seed);
+        run<4>(1, seed); run<2>(1, seed); run<4>(2, seed); run<4>(4, seed);
     }
     return 0;
 }
