@@ -52,6 +52,8 @@ def parse():
                     help='run the embedder on padded batches with PyTorch ops instead of the unpadded librag_hip path')
     ap.add_argument('--embed-fp32-gemm', action='store_true',
                     help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
+    ap.add_argument('--ce-fused-attn-out', action='store_true',
+                    help='tuning aid: attention-output projection + LayerNorm inside the feed-forward kernel')
     ap.add_argument('--ce-library-mlp', action='store_true',
                     help='tuning aid: feed-forward blocks as library GEMMs + tail kernels instead of rag_enc_mlp_dev')
     ap.add_argument('--ce-fused-linear', action='store_true',
@@ -251,6 +253,7 @@ def main():
                                native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
     ce.bert.fused_linear = bool(args.ce_fused_linear)
     ce.bert.fused_mlp = not args.ce_library_mlp
+    ce.bert.fused_tail = bool(args.ce_fused_attn_out)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
                              rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)

@@ -82,6 +82,12 @@ struct MlpParams {
     int64_t M;
     int I;
     float eps;
+    // attention-output projection in front of the block (PROJ kernels): x above is then the layer's input
+    const bf16* ctx;      // [M][384] attention output
+    const bf16* wo;       // [384][384]
+    const bf16* bo;       // [384]
+    const bf16* gamma1;   // [384]
+    const bf16* beta1;    // [384]
 };
 
 // One wave-instruction of a direct-to-LDS load: lane l's 16 bytes at gbase + voff land at LDS byte
@@ -107,6 +113,10 @@ __device__ __forceinline__ void lds_read16(T& dst, uint32_t addr) {
 template <int N, typename T>
 __device__ __forceinline__ void lds_wait(T& a, T& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N, typename T>
+__device__ __forceinline__ void lds_wait(T& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
 }
 template <int... Is, typename F>
 __device__ __forceinline__ void unrolled(std::integer_sequence<int, Is...>, F&& f) {
@@ -145,6 +155,7 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     return gelu_tail(v, c, s, p);
 }
 
+template <bool PROJ>
 __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ML_STAMP(tk0);
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     //   H^T accumulator registers 8t..8t+7 of a lane are units 16t + 8h + 0..7, the natural k order of
     //   W2; piece j of the row sits at j ^ (q & 15).
     //   W2 image row f (feature) holds the chunk's 32 units, piece j at j ^ ((f >> 2) & 3).
-    uint32_t off1[ML_W_DMAS], off2[ML_W_DMAS];                // per-lane source byte offsets inside a chunk
+    uint32_t off1[ML_W_DMAS], off2[ML_W_DMAS], offo[ML_W_DMAS];   // per-lane source byte offsets inside a chunk
 #pragma unroll
     for (int i = 0; i < ML_W_DMAS; ++i) {
         const int L = 64 * (wave + 4 * i) + lane;             // piece index inside the image
@@ -173,6 +184,10 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         off1[i] = (uint32_t)((unit * ML_HID + j1 * 8) * 2);
         const int f = L / 4, j2 = (L % 4) ^ ((f >> 2) & 3);
         off2[i] = (uint32_t)((f * p.I + j2 * 8) * 2);
+        // Wo image (PROJ): the W2 image shape, but row f holds output feature (f with bits 2 and 3 swapped),
+        // so that the accumulators of the projection are the X fragments of the first product
+        const int fo = (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1);
+        offo[i] = (uint32_t)((fo * ML_HID + j2 * 8) * 2);
     }
     auto dma_w1 = [&](int c, int buf) {                      // chunk c of W1 -> W1 buffer buf
         const bf16* g = p.w1 + (size_t)c * ML_C * ML_HID;
@@ -188,19 +203,20 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     const int last = n_chunks - 1;
     dma_w1(0, 0);
     dma_w1(min(1, last), 1);
-    dma_w2(0, 0);
+    if constexpr (!PROJ) dma_w2(0, 0);
     for (int i = tid; i < p.I; i += ML_NT) *reinterpret_cast<float*>(smem + ML_OFF_B1 + 4 * i) = (float)p.b1[i];
-    if (tid < 3 * (ML_HID / 8)) {                           // b2 | gamma | beta behind b1, bf16
-        const int vsel = tid / (ML_HID / 8), piece = tid % (ML_HID / 8);
-        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : p.beta;
+    for (int i = tid; i < (PROJ ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, bf16
+        const int vsel = i / (ML_HID / 8), piece = i % (ML_HID / 8);
+        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : vsel == 2 ? p.beta : vsel == 3 ? p.bo : vsel == 4 ? p.gamma1 : p.beta1;
         *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (vsel * ML_HID + piece * 8)) =
             *reinterpret_cast<const bf16x8*>(src + piece * 8);
     }
 
     // ---- the wave's 32 rows of X as B fragments: lane (r, h) holds X[tok][16t + 8h .. + 7]
+    // (PROJ: the rows of the attention output first; X is then computed below)
     bf16x8 xf[ML_KS];
     {
-        const bf16* xrow = p.x + tok_ld * ML_HID + 8 * h;
+        const bf16* xrow = (PROJ ? p.ctx : p.x) + tok_ld * ML_HID + 8 * h;
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
     }
@@ -247,6 +263,80 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) yacc[m][i] = 0.f;
 
+    if constexpr (PROJ) {
+        // ---- attention-output projection and its LayerNorm:  X = LN1(x_in + ctx Wo^T + bo).
+        // Y1^T[feature][token] = Wo . ctx^T into the same twelve accumulator tiles, Wo streamed through
+        // the two W2 buffers in 12 slices of 32 input columns (the W2 image shape: 24 MFMAs per slice,
+        // fragment reads issued ML_PO MFMAs ahead).  With the Wo rows in the swapped order, registers
+        // 8t..8t+7 of tile m are features 32m + 16t + 8h + 0..7 of the lane's token: after the LayerNorm
+        // they are, converted to bf16, exactly the fragment xf[2m + t].
+        constexpr int ML_PO = 6;
+        auto dma_wo = [&](int kc, int buf, int i) {
+            lds_dma16(lds0 + ML_OFF_W2 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), p.wo + kc * ML_C, offo[i]);
+        };
+#pragma unroll
+        for (int i = 0; i < ML_W_DMAS; ++i) dma_wo(0, 0, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto slice = [&](auto kc_c) {
+            constexpr int KC = decltype(kc_c)::value, BUF = KC & 1;
+            u32x4 q[ML_PO + 1];
+            auto issue = [&](auto s_c) {
+                constexpr int S = decltype(s_c)::value;
+                lds_read16<BUF * ML_W_BYTES + (S % ML_YT) * (32 * ML_C * 2)>(q[S % (ML_PO + 1)], l2[S / ML_YT]);
+            };
+            auto step = [&](auto s_c) {
+                constexpr int S = decltype(s_c)::value;
+                if constexpr (S < ML_W_DMAS && KC + 1 < ML_HID / ML_C) dma_wo(KC + 1, BUF ^ 1, S);
+                if constexpr (S + ML_PO < ML_KS) issue(std::integral_constant<int, S + ML_PO>{});
+                constexpr int newer = ML_KS - 1 - S < ML_PO ? ML_KS - 1 - S : ML_PO;
+                lds_wait<newer>(q[S % (ML_PO + 1)]);
+                constexpr int M = S % ML_YT, T = S / ML_YT;
+                yacc[M] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q[S % (ML_PO + 1)]),
+                                                                  xf[2 * KC + T], yacc[M], 0, 0, 0);
+            };
+            unrolled(std::make_integer_sequence<int, ML_PO>{}, issue);
+            unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        unrolled(std::make_integer_sequence<int, ML_HID / ML_C>{}, slice);
+        dma_w2(0, 0);                                         // both W2 buffers are free again
+        // bias, residual, LayerNorm; the result replaces the ctx fragments in xf
+        const unsigned char* v1 = smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (3 * ML_HID) + 16 * h;   // bo | gamma1 | beta1
+        const bf16* xin = p.x + tok_ld * ML_HID + 8 * h;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < ML_KS; ++t) {
+            const bf16x8 xr = *reinterpret_cast<const bf16x8*>(xin + 16 * t);
+            const bf16x8 bb = *reinterpret_cast<const bf16x8*>(v1 + 32 * t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xr[j];
+                yacc[t >> 1][8 * (t & 1) + j] = v;
+                sum += v;
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / (float)ML_HID;
+        float sq = 0.f;
+#pragma unroll
+        for (int m = 0; m < ML_YT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float d = yacc[m][i] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq / (float)ML_HID + p.eps);
+#pragma unroll
+        for (int t = 0; t < ML_KS; ++t) {
+            const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(v1 + 2 * ML_HID + 32 * t);
+            const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(v1 + 4 * ML_HID + 32 * t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xf[t][j] = (bf16)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+                yacc[t >> 1][8 * (t & 1) + j] = 0.f;
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -430,6 +520,29 @@ extern "C" int rag_enc_mlp_debug(unsigned long long* out8) {
 }
 #endif
 
+namespace {
+
+int launch_mlp(const MlpParams& p, bool proj, hipStream_t stream, const char* who) {
+    RAG_REQUIRE(ceil_div64(p.M, ML_BM) < (1ll << 31), RAG_ELIMIT, "%s: too many rows", who);
+    const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)p.I + 6 * ML_HID * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int max_lds = ML_OFF_B1 + 4 * ML_MAX_I + 6 * ML_HID * 2;
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
+    if (proj)
+        hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(ML_NT), lds_bytes, stream, p);
+    else
+        hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(ML_NT), lds_bytes, stream, p);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+}  // namespace
+
 extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                                const void* d_gamma, const void* d_beta, float eps, int64_t m, int32_t hidden,
                                int32_t intermediate, int32_t dtype, void* d_y, void* stream_) {
@@ -441,20 +554,32 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma && d_beta && d_y, RAG_EINVAL, "rag_enc_mlp: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_mlp: y must not alias x (x is read again as the residual)");
-    RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_mlp: too many rows");
-    const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)intermediate + 3 * ML_HID * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ML_OFF_B1 + 4 * ML_MAX_I + 3 * ML_HID * 2));
-        attr_set = true;
-    }
-    MlpParams p;
+    MlpParams p = {};
     p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
     p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.y = (bf16*)d_y;
     p.M = m; p.I = intermediate; p.eps = eps;
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3((unsigned)ceil_div64(m, ML_BM)), dim3(ML_NT), lds_bytes,
-                       (hipStream_t)stream_, p);
-    RAG_HIP_TRY(hipGetLastError());
-    return RAG_OK;
+    return launch_mlp(p, false, (hipStream_t)stream_, "rag_enc_mlp");
+}
+
+extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_wo, const void* d_bo,
+                                        const void* d_gamma1, const void* d_beta1, const void* d_w1, const void* d_b1,
+                                        const void* d_w2, const void* d_b2, const void* d_gamma2, const void* d_beta2,
+                                        float eps, int64_t m, int32_t hidden, int32_t intermediate, int32_t dtype,
+                                        void* d_y, void* stream_) {
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attn_out_mlp: bf16 only");
+    RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_attn_out_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
+    RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
+                "rag_enc_attn_out_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I,
+                intermediate);
+    RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_attn_out_mlp: negative row count");
+    if (m == 0) return RAG_OK;
+    RAG_REQUIRE(d_ctx && d_x && d_wo && d_bo && d_gamma1 && d_beta1 && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma2 && d_beta2 && d_y,
+                RAG_EINVAL, "rag_enc_attn_out_mlp: null pointer");
+    MlpParams p = {};
+    p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
+    p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma2; p.beta = (const bf16*)d_beta2; p.y = (bf16*)d_y;
+    p.M = m; p.I = intermediate; p.eps = eps;
+    p.ctx = (const bf16*)d_ctx; p.wo = (const bf16*)d_wo; p.bo = (const bf16*)d_bo;
+    p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
+    return launch_mlp(p, true, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
 }

@@ -105,6 +105,7 @@ class BertEncoder(nn.Module):
         self._split_cache = {}
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
+        self.fused_tail = False      # ... and the attention-output projection + LayerNorm in the same kernel
 
     @staticmethod
     def pack(input_ids, attention_mask, token_type_ids=None):
@@ -169,10 +170,15 @@ class BertEncoder(nn.Module):
             if first_token_only and li == last and x.dtype == torch.bfloat16:
                 ctx = rag_hip.enc_attention_packed_first_dev(l.qkv(x), cu_seqlens, max_seq_len, l.heads)
                 x = x[cu_seqlens[:-1].long()]
+                if self._layer_tail_fused(l, x):
+                    return self._layer_tail(l, ctx, x)
                 x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                                   l.attn_norm.eps)
                 return self._feed_forward(l, x, lin)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
+            if self._layer_tail_fused(l, x):
+                x = self._layer_tail(l, ctx, x)
+                continue
             if self.fused_linear and rag_hip.enc_linear_supported(ctx, l.attn_out.weight) and x.shape[1] == 384:
                 # output projection with bias + residual + LayerNorm in the GEMM epilogue
                 x = rag_hip.enc_linear_dev(ctx, l.attn_out.weight, l.attn_out.bias,
@@ -183,6 +189,20 @@ class BertEncoder(nn.Module):
                                                   l.attn_norm.eps)
             x = self._feed_forward(l, x, lin)
         return x
+
+    def _layer_tail_fused(self, l, x):
+        import rag_hip
+        return (self.fused_mlp and self.fused_tail and l.attn_norm.eps == l.ffn_norm.eps
+                and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight)
+                and l.attn_out.weight.dtype == torch.bfloat16)
+
+    def _layer_tail(self, l, ctx, x):
+        """Everything after self-attention (output projection, residual + LayerNorm, feed-forward
+        block, residual + LayerNorm) in one kernel."""
+        import rag_hip
+        return rag_hip.enc_attn_out_mlp_dev(ctx, x.contiguous(), l.attn_out.weight, l.attn_out.bias, l.attn_norm.weight,
+                                            l.attn_norm.bias, l.ffn_in.weight, l.ffn_in.bias, l.ffn_out.weight,
+                                            l.ffn_out.bias, l.ffn_norm.weight, l.ffn_norm.bias, l.ffn_norm.eps)
 
     def _feed_forward(self, l, x, lin):
         """LayerNorm(x + W2 GELU(W1 x)): one kernel where rag_enc_mlp_dev covers the shape, else

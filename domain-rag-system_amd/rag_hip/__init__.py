@@ -70,6 +70,7 @@ SIGNATURES = {
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
@@ -733,6 +734,28 @@ def enc_mlp_dev(x, w1, b1, w2, b2, gamma, beta, eps=1e-12):
     check(lib().rag_enc_mlp_dev(_ptr(x, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma, bf),
                                 _ptr(beta, bf), float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()),
           'rag_enc_mlp_dev')
+    return y
+
+
+def enc_attn_out_mlp_dev(ctx, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps=1e-12):
+    """Everything of a BERT layer after self-attention in one kernel (rag_enc_attn_out_mlp_dev):
+    x1 = LN(x + ctx @ wo.T + bo), y = LN(x1 + GELU(x1 @ w1.T + b1) @ w2.T + b2); ctx, x [M, 384] bf16."""
+    import torch
+    m, hid = x.shape
+    inter = w1.shape[0]
+    if tuple(ctx.shape) != (m, hid) or tuple(wo.shape) != (hid, hid):
+        raise ValueError("ctx must be [M, H] and wo [H, H]")
+    if tuple(w1.shape) != (inter, hid) or tuple(w2.shape) != (hid, inter) or tuple(b1.shape) != (inter,):
+        raise ValueError("w1 must be [I, H], w2 [H, I] and b1 [I]")
+    for v in (bo, gamma1, beta1, b2, gamma2, beta2):
+        if tuple(v.shape) != (hid,):
+            raise ValueError("bo, b2 and the LayerNorm vectors must be [H]")
+    y = torch.empty_like(x)
+    bf = torch.bfloat16
+    check(lib().rag_enc_attn_out_mlp_dev(_ptr(ctx, bf), _ptr(x, bf), _ptr(wo, bf), _ptr(bo, bf), _ptr(gamma1, bf),
+                                         _ptr(beta1, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf),
+                                         _ptr(gamma2, bf), _ptr(beta2, bf), float(eps), m, hid, inter, DTYPE_BF16,
+                                         _ptr(y), _stream()), 'rag_enc_attn_out_mlp_dev')
     return y
 
 

@@ -298,6 +298,19 @@ int rag_enc_linear_dev(const void* d_x, const void* d_w, const void* d_bias, int
 int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2,
                     const void* d_b2, const void* d_gamma, const void* d_beta, float eps, int64_t m,
                     int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y, void* stream);
+/* The rest of a BERT layer after self-attention in one kernel (bf16, fp32 accumulation):
+ *   x1   = LayerNorm(x[m] + ctx[m] wo^T + bo) * gamma1 + beta1      (BertSelfOutput)
+ *   y[m] = LayerNorm(x1 + GELU(x1 w1^T + b1) w2^T + b2) * gamma2 + beta2
+ * ctx = attention output, x = the layer's input, both [m][hidden]; wo [hidden][hidden]; the other
+ * arguments as in rag_enc_mlp_dev (same reference path, src/reranker/rerank.py:79-84).  x1 is kept
+ * on chip, rounded to bf16 as the layer-by-layer forward stores it.  y may alias x or ctx only if
+ * the caller no longer needs them: rows are read before they are written by the same workgroup. */
+int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_wo, const void* d_bo,
+                             const void* d_gamma1, const void* d_beta1, const void* d_w1,
+                             const void* d_b1, const void* d_w2, const void* d_b2,
+                             const void* d_gamma2, const void* d_beta2, float eps, int64_t m,
+                             int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y,
+                             void* stream);
 /* x := GELU(x) (exact erf form, BERT's "gelu"), in place over n elements (n % 8 == 0).  */
 int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
 /* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32

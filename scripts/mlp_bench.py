@@ -43,6 +43,27 @@ def main():
     fl = 4.0 * args.tokens * 384 * args.inter
     print(f'feed-forward block: tokens={args.tokens} inter={args.inter} {ms:.3f} ms, {fl / ms / 1e9:.0f} TFLOP/s, '
           f'{args.tokens * 384 * 2 * 2 / ms / 1e6:.0f} GB/s algorithmic', flush=True)
+    lo = torch.nn.Linear(384, 384, device=dev, dtype=bf)
+    ctx = torch.randn((args.tokens, 384), generator=g, device=dev).to(bf)
+
+    def layer_by_layer():
+        x1 = rag_hip.enc_add_layernorm_dev(lo(ctx), x, gamma, beta, 1e-12)
+        return rag_hip.enc_mlp_dev(x1, l1.weight, l1.bias, l2.weight, l2.bias, gamma, beta)
+
+    def one_kernel():
+        return rag_hip.enc_attn_out_mlp_dev(ctx, x, lo.weight, lo.bias, gamma, beta, l1.weight, l1.bias, l2.weight,
+                                            l2.bias, gamma, beta)
+    with torch.no_grad():
+        for name, fn in (('projection GEMM + LayerNorm kernel + feed-forward kernel', layer_by_layer),
+                         ('attention output + feed-forward in one kernel', one_kernel)):
+            fn()
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(args.iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            print(f'{name}: {a.elapsed_time(b) / args.iters:.3f} ms', flush=True)
     rag_hip.check_faults()
     import ctypes
     L = rag_hip.lib()

@@ -45,6 +45,36 @@ def test_mlp_block_matches_exact(m, inter):
     assert float(err.mean()) <= float((unf.double() - ref).abs().mean()) * 1.05
 
 
+@pytest.mark.parametrize('m,inter', [(1000, 1536), (128, 1536), (1, 1536), (129, 64), (4097, 1536)])
+def test_attention_output_and_mlp_block_matches_exact(m, inter):
+    """Attention-output projection + LayerNorm + feed-forward block in one kernel."""
+    import rag_hip
+    x, w1, b1, w2, b2, gamma2, beta2 = _layer(m, inter, 11 * m + inter)
+    dev, bf = x.device, torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(5 * m + inter)
+    ctx = torch.randn((m, 384), generator=g, device=dev).to(bf)
+    wo = (torch.randn((384, 384), generator=g, device=dev) * 0.05).to(bf)
+    bo = (torch.randn((384,), generator=g, device=dev) * 0.1).to(bf)
+    gamma1 = (1 + 0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    beta1 = (0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    y = rag_hip.enc_attn_out_mlp_dev(ctx, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, 1e-12)
+    d = torch.float64
+    v = x.to(d) + ctx.to(d) @ wo.to(d).t() + bo.to(d)
+    x1 = torch.nn.functional.layer_norm(v, (384,), gamma1.to(d), beta1.to(d), 1e-12)
+    # the kernel rounds x1 to bf16 where the layer-by-layer forward stores it; follow that rounding
+    x1b = x1.to(bf)
+    ref = _exact(x1b, w1, b1, w2, b2, gamma2, beta2)
+    err = (y.double() - ref).abs()
+    # x1 is O(1) with a bf16 ulp of 8e-3: a one-ulp difference in a few of its 384 values moves the output
+    assert float(err.mean()) < 6e-3
+    assert float(err.max()) < 8e-2
+    # against the layer-by-layer route on the same inputs
+    lin = (ctx @ wo.t() + bo).contiguous()
+    x1u = rag_hip.enc_add_layernorm_dev(lin, x, gamma1, beta1, 1e-12)
+    yu = rag_hip.enc_mlp_dev(x1u, w1, b1, w2, b2, gamma2, beta2, 1e-12)
+    assert float(err.mean()) <= float((yu.double() - ref).abs().mean()) * 1.1 + 1e-4
+
+
 def test_mlp_rows_are_independent():
     """A row's result does not depend on which workgroup or lane computes it."""
     import rag_hip
