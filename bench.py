@@ -28,6 +28,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
 
 
 def parse():
@@ -274,6 +275,7 @@ def main():
         step(queries[i])
     barrier()
     dense.profile(True)
+    rag_hip.enc_mlp_profile(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(queries[args.warmup + i])
@@ -281,6 +283,8 @@ def main():
     dt = time.perf_counter() - t0
     scan_ms = dense.profile_read()
     dense.profile(False)
+    mlp_ms, mlp_rows = rag_hip.enc_mlp_profile_read()
+    rag_hip.enc_mlp_profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -322,6 +326,20 @@ def main():
             roofline['traffic'] = round(float(pmc['traffic_bytes_per_launch']) / 1e9, 2)
             roofline['traffic_unit'] = 'GB per launch (rocprofv3 --pmc, separate passes)'
 
+    # the kernel with the largest share of a step: the cross-encoder's feed-forward block.  Algorithmic
+    # work of a launch: 4 * rows * hidden * intermediate FLOPs (two products), 2 * rows * hidden * 2 bytes.
+    ce_cfg = ce.bert.config
+    roofline_ff = None
+    if len(mlp_ms):
+        ff_flops = 4.0 * float(mlp_rows.sum()) * ce_cfg.hidden_size * ce_cfg.intermediate_size
+        ff_s = float(mlp_ms.sum()) / 1e3
+        roofline_ff = {'kernel': 'mlp_fused_kernel', 'bound': 'mfma', 'achieved': round(ff_flops / ff_s / 1e12, 1),
+                       'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': round(ff_flops / ff_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                       'launches_per_step': len(mlp_ms) // max(args.steps, 1),
+                       'ms_per_step': round(float(mlp_ms.sum()) / max(args.steps, 1), 2),
+                       'algorithmic_gbs': round(4.0 * float(mlp_rows.sum()) * ce_cfg.hidden_size / ff_s / 1e9, 1)}
+
     result = {
         'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
         'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
@@ -340,6 +358,7 @@ def main():
                    'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU'},
         'stage_ms_per_step': stage_ms,
         'roofline': roofline,
+        'roofline_feed_forward': roofline_ff,
     }
     if args.cpu_queries > 0 and world == 1:
         bi_cpu, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', 'cpu')

@@ -522,6 +522,17 @@ extern "C" int rag_enc_mlp_debug(unsigned long long* out8) {
 
 namespace {
 
+// Measurement aid: while enabled, every launch is bracketed by a HIP event pair on its stream.
+// One state per process (one process drives one GPU here); not thread safe.
+struct MlpProfile {
+    static constexpr int RING = 1024;
+    bool on = false;
+    int n = 0;
+    hipEvent_t ev0[RING], ev1[RING];
+    int64_t rows[RING];
+};
+MlpProfile g_prof;
+
 int launch_mlp(const MlpParams& p, bool proj, hipStream_t stream, const char* who) {
     RAG_REQUIRE(ceil_div64(p.M, ML_BM) < (1ll << 31), RAG_ELIMIT, "%s: too many rows", who);
     const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)p.I + 6 * ML_HID * 2;
@@ -533,11 +544,17 @@ int launch_mlp(const MlpParams& p, bool proj, hipStream_t stream, const char* wh
         attr_set = true;
     }
     const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
+    const bool timed = g_prof.on && g_prof.n < MlpProfile::RING;
+    if (timed) RAG_HIP_TRY(hipEventRecord(g_prof.ev0[g_prof.n], stream));
     if (proj)
         hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(ML_NT), lds_bytes, stream, p);
     else
         hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(ML_NT), lds_bytes, stream, p);
     RAG_HIP_TRY(hipGetLastError());
+    if (timed) {
+        RAG_HIP_TRY(hipEventRecord(g_prof.ev1[g_prof.n], stream));
+        g_prof.rows[g_prof.n++] = p.M;
+    }
     return RAG_OK;
 }
 
@@ -582,4 +599,37 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
     p.ctx = (const bf16*)d_ctx; p.wo = (const bf16*)d_wo; p.bo = (const bf16*)d_bo;
     p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
     return launch_mlp(p, true, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
+}
+
+extern "C" int rag_enc_mlp_profile(int32_t enable) {
+    if (enable && !g_prof.on) {
+        for (int i = 0; i < MlpProfile::RING; ++i) {
+            RAG_HIP_TRY(hipEventCreate(&g_prof.ev0[i]));
+            RAG_HIP_TRY(hipEventCreate(&g_prof.ev1[i]));
+        }
+        g_prof.on = true;
+    }
+    if (!enable && g_prof.on) {
+        for (int i = 0; i < MlpProfile::RING; ++i) {
+            (void)hipEventDestroy(g_prof.ev0[i]);
+            (void)hipEventDestroy(g_prof.ev1[i]);
+        }
+        g_prof.on = false;
+    }
+    g_prof.n = 0;
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_mlp_profile_read(float* out_ms, int64_t* out_rows, int32_t max_n, int32_t* out_n) {
+    RAG_REQUIRE(out_ms && out_rows && out_n, RAG_EINVAL, "rag_enc_mlp_profile_read: null argument");
+    int n = g_prof.on ? g_prof.n : 0;
+    if (n > max_n) n = max_n;
+    for (int i = 0; i < n; ++i) {
+        RAG_HIP_TRY(hipEventSynchronize(g_prof.ev1[i]));
+        RAG_HIP_TRY(hipEventElapsedTime(&out_ms[i], g_prof.ev0[i], g_prof.ev1[i]));
+        out_rows[i] = g_prof.rows[i];
+    }
+    *out_n = n;
+    g_prof.n = 0;
+    return RAG_OK;
 }

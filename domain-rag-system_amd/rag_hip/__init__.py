@@ -70,6 +70,8 @@ SIGNATURES = {
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_mlp_profile': (_i32, [_i32]),
+    'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
@@ -735,6 +737,20 @@ def enc_mlp_dev(x, w1, b1, w2, b2, gamma, beta, eps=1e-12):
                                 _ptr(beta, bf), float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()),
           'rag_enc_mlp_dev')
     return y
+
+
+def enc_mlp_profile(enable=True):
+    """Measurement aid: record a HIP event pair around every feed-forward kernel launch."""
+    check(lib().rag_enc_mlp_profile(1 if enable else 0), 'rag_enc_mlp_profile')
+
+
+def enc_mlp_profile_read():
+    """(durations in ms, row counts) of the feed-forward kernel launches since the last read."""
+    ms = np.zeros(1024, np.float32)
+    rows = np.zeros(1024, np.int64)
+    n = _i32(0)
+    check(lib().rag_enc_mlp_profile_read(ms.ctypes.data, rows.ctypes.data, 1024, C.byref(n)), 'rag_enc_mlp_profile_read')
+    return ms[:n.value].copy(), rows[:n.value].copy()
 
 
 def enc_attn_out_mlp_dev(ctx, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps=1e-12):

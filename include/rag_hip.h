@@ -311,6 +311,12 @@ int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_w
                              const void* d_gamma2, const void* d_beta2, float eps, int64_t m,
                              int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y,
                              void* stream);
+/* Measurement aid (no counterpart in the reference): while enabled, every launch of the
+ * feed-forward kernel (rag_enc_mlp_dev, rag_enc_attn_out_mlp_dev) records a HIP event pair on
+ * its stream, up to 1024 launches; rag_enc_mlp_profile_read waits for them and returns their
+ * durations in ms and row counts.  One state per process.                               */
+int rag_enc_mlp_profile(int32_t enable);
+int rag_enc_mlp_profile_read(float* out_ms, int64_t* out_rows, int32_t max_n, int32_t* out_n);
 /* x := GELU(x) (exact erf form, BERT's "gelu"), in place over n elements (n % 8 == 0).  */
 int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
 /* Split-precision operand for running an fp32 GEMM on the bf16 matrix cores: each fp32
