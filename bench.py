@@ -339,6 +339,12 @@ def main():
                        'launches_per_step': len(mlp_ms) // max(args.steps, 1),
                        'ms_per_step': round(float(mlp_ms.sum()) / max(args.steps, 1), 2),
                        'algorithmic_gbs': round(4.0 * float(mlp_rows.sum()) * ce_cfg.hidden_size / ff_s / 1e9, 1)}
+        ff_pmc = os.path.join(ROOT, 'profiles', 'pmc_mlp.json')
+        if os.path.exists(ff_pmc):
+            with open(ff_pmc) as f:
+                per_row = float(json.load(f)['traffic_bytes_per_row'])
+            roofline_ff['traffic'] = round(per_row * float(mlp_rows.mean()) / 1e9, 2)
+            roofline_ff['traffic_unit'] = 'GB per launch (bytes per row from rocprofv3 --pmc passes of scripts/mlp_bench.py)'
 
     result = {
         'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
