@@ -22,9 +22,10 @@
 // c+2, GELU of c+1, second product of c).  W1 / W2 chunks are double buffered in LDS, filled by
 // direct-to-LDS loads from L2 (the images are XOR-swizzled, not padded: conflict-free 16-byte
 // reads); the fragment reads are issued from the source three k-steps ahead of their MFMAs.  The
-// epilogue adds bias and the residual (the block's own input, still in registers), takes the
+// W2 rows are staged in the same swapped order, so Y^T comes out in the layout of the X fragments:
+// the epilogue adds bias and the residual (the block's own input, still in registers), takes the
 // LayerNorm statistics of a token from the lane and its partner in the other half-wave, and
-// stores bf16.
+// stores bf16 in 16-byte pieces.
 //
 // Behind CrossEncoderReranker.score_pairs (reference src/reranker/rerank.py:79-84): the
 // intermediate / output sub-layers of the BertForSequenceClassification forward that
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     //   W1 image row q holds unit (q with bits 2 and 3 swapped) of the chunk: with that row order the
     //   H^T accumulator registers 8t..8t+7 of a lane are units 16t + 8h + 0..7, the natural k order of
     //   W2; piece j of the row sits at j ^ (q & 15).
-    //   W2 image row f (feature) holds the chunk's 32 units, piece j at j ^ ((f >> 2) & 3).
+    //   W2 image row f holds the chunk's 32 units of feature (f with bits 2 and 3 swapped), piece j at
+    //   j ^ ((f >> 2) & 3).
     uint32_t off1[ML_W_DMAS], off2[ML_W_DMAS], offo[ML_W_DMAS];   // per-lane source byte offsets inside a chunk
 #pragma unroll
     for (int i = 0; i < ML_W_DMAS; ++i) {
@@ -182,11 +184,11 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         const int q = L / 48, j1 = (L % 48) ^ (q & 15);
         const int unit = (q & ~12) | ((q & 4) << 1) | ((q & 8) >> 1);
         off1[i] = (uint32_t)((unit * ML_HID + j1 * 8) * 2);
+        // W2 and Wo (PROJ) images: row f holds output feature (f with bits 2 and 3 swapped), so that the
+        // accumulators of Y^T — and of the projection — come out in the layout of the X fragments
         const int f = L / 4, j2 = (L % 4) ^ ((f >> 2) & 3);
-        off2[i] = (uint32_t)((f * p.I + j2 * 8) * 2);
-        // Wo image (PROJ): the W2 image shape, but row f holds output feature (f with bits 2 and 3 swapped),
-        // so that the accumulators of the projection are the X fragments of the first product
         const int fo = (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1);
+        off2[i] = (uint32_t)((fo * p.I + j2 * 8) * 2);
         offo[i] = (uint32_t)((fo * ML_HID + j2 * 8) * 2);
     }
     auto dma_w1 = [&](int c, int buf) {                      // chunk c of W1 -> W1 buffer buf
@@ -451,34 +453,20 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     ML_STAMP(tl1);
     const unsigned long long tpro = tl0 - tk0;
 #endif
-    // ---- epilogue: yacc[m][i] is feature 32m + (i&3) + 8(i>>2) + 4h of token `tok`.  The residual is
-    // the block's own input, still in xf: lane (r, h) holds columns 16t + 8h + 0..7 of its token and needs
-    // columns 8q' + 4h + 0..3 for every q' — half of them are its own, the other half sit in the partner
-    // lane of the other half-wave (one exchange of two registers per k-step, no second trip to memory).
-    // b2, gamma and beta come from LDS.
-    const unsigned char* vecs = smem + ML_OFF_B1 + 4 * (size_t)p.I + 8 * h;
-    auto bf2f = [](uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); };
+    // ---- epilogue.  The W2 image rows are in the same swapped order as the W1 rows, so registers
+    // 8t'..8t'+7 of tile m are features 32m + 16t' + 8h + 0..7 of the lane's token: the layout of the X
+    // fragments.  The residual (the block's own input) is therefore xf[2m + t'] itself, and bias, gamma,
+    // beta (LDS) and the output are 16-byte accesses.
+    const unsigned char* vecs = smem + ML_OFF_B1 + 4 * (size_t)p.I + 16 * h;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < ML_KS; ++t) {
-        const u32x4 d = __builtin_bit_cast(u32x4, xf[t]);
-        const uint32_t r0 = (uint32_t)__shfl_xor((int)(h ? d[0] : d[2]), 32, 64);
-        const uint32_t r1 = (uint32_t)__shfl_xor((int)(h ? d[1] : d[3]), 32, 64);
-        const uint32_t w[2][2] = {{h ? r0 : d[0], h ? r1 : d[1]}, {h ? d[2] : r0, h ? d[3] : r1}};
-        const int m = t >> 1;
+        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(vecs + 32 * t);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = 2 * (t & 1) + k;
-            const bf16x4 bb = *reinterpret_cast<const bf16x4*>(vecs + 2 * (32 * m + 8 * q));
-            float rr[4];
-            bf2f(w[k][0], rr[0], rr[1]);
-            bf2f(w[k][1], rr[2], rr[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = yacc[m][4 * q + j] + (float)bb[j] + rr[j];
-                yacc[m][4 * q + j] = v;
-                sum += v;
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float v = yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xf[t][j];
+            yacc[t >> 1][8 * (t & 1) + j] = v;
+            sum += v;
         }
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -492,17 +480,15 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     const float rstd = rsqrtf(sq / (float)ML_HID + p.eps);
     const bool live = tok < p.M;
 #pragma unroll
-    for (int m = 0; m < ML_YT; ++m)
+    for (int t = 0; t < ML_KS; ++t) {
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(vecs + 2 * ML_HID + 32 * t);
+        const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(vecs + 4 * ML_HID + 32 * t);
+        bf16x8 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = 32 * m + 8 * q;
-            const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(vecs + 2 * (ML_HID + n));
-            const bf16x4 be4 = *reinterpret_cast<const bf16x4*>(vecs + 2 * (2 * ML_HID + n));
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)((yacc[m][4 * q + j] - mean) * rstd * (float)g4[j] + (float)be4[j]);
-            if (live) *reinterpret_cast<bf16x4*>(p.y + tok * ML_HID + n + 4 * h) = o;
-        }
+        for (int j = 0; j < 8; ++j)
+            o[j] = (bf16)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+        if (live) *reinterpret_cast<bf16x8*>(p.y + tok * ML_HID + 16 * t + 8 * h) = o;
+    }
 #if ML_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ML_STAMP(tk1);
