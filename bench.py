@@ -75,7 +75,7 @@ def log(*a):
 def build_shard(args, rank, world, dev, dist):
     """Synthetic shard of `args.rows` rows: embeddings, postings, chunk tokens, canon."""
     import rag_hip
-    from indexing.bm25_indexer import build_arrays
+    from indexing.bm25_indexer import build_arrays_device
     from tests import synth
     n, dim, v = args.rows, args.dim, args.vocab
     row_base = rank * n
@@ -99,7 +99,7 @@ def build_shard(args, rank, world, dev, dist):
         dist.all_reduce(tdf)
         dist.all_reduce(tot)
         stats = dict(df=tdf.cpu().numpy(), total_len=int(tot[0]), n_docs=int(tot[1]))
-    arr = build_arrays(term, doc, ln, v, 1.5, 0.75, global_stats=stats)
+    arr = build_arrays_device(term, doc, ln, v, 1.5, 0.75, global_stats=stats, device=dev)
     bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n, row_base=row_base)
     log(f'[rank {rank}] bm25 shard: {arr.rows.shape[0]} postings in {time.time() - t0:.1f}s')
 

@@ -46,6 +46,8 @@ class Bm25Arrays:
     def impacts(self):
         """tf*(k1+1) / (tf + k1*(1 - b + b*doc_len/avgdl)), evaluated in the operand order of
         the upstream expression so every posting's value is bit-identical to it."""
+        if getattr(self, '_impacts', None) is not None:      # computed on the device at build time
+            return self._impacts
         k1, b = self.k1, self.b
         norm = k1 * (1 - b + b * self.doc_len / self.avgdl)
         tf = self.tf.astype(np.int64)
@@ -75,7 +77,15 @@ def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=None):
         df = np.asarray(global_stats['df'], np.int64)
         n_docs = int(global_stats['n_docs'])
         total_len = int(global_stats['total_len'])
-    # idf with libm's log, summed in vocabulary (first appearance) order
+    idf = _idf(df, n_docs, v)
+    avgdl = total_len / n_docs
+    assert doc_len.shape[0] == n_local
+    return Bm25Arrays(vocab, indptr, rows, tf.astype(np.uint32), idf, doc_len.astype(np.int64), avgdl, k1, b)
+
+
+def _idf(df, n_docs, v):
+    """idf with libm's log, summed in vocabulary (first appearance) order; negative values are
+    replaced by epsilon * mean idf, as rank_bm25's BM25Okapi does."""
     idf = np.zeros(v, np.float64)
     total = 0
     log = math.log
@@ -89,9 +99,45 @@ def build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=None):
     if present:
         floor = _EPSILON * (total / present)
         idf[(idf < 0) & (df > 0)] = floor
-    avgdl = total_len / n_docs
-    assert doc_len.shape[0] == n_local
-    return Bm25Arrays(vocab, indptr, rows, tf.astype(np.uint32), idf, doc_len.astype(np.int64), avgdl, k1, b)
+    return idf
+
+
+def build_arrays_device(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=None, device='cuda'):
+    """build_arrays with the counting, the sort into term-major order and the impacts done on the
+    GPU (rag_bm25_build_dev, rag_bm25_impacts_dev); same arguments, same result bit for bit.  The
+    occurrences must be grouped by document in ascending order (they are when documents are
+    tokenised one after the other); otherwise they are stably sorted by document first."""
+    import torch
+    n_docs = int(doc_len.shape[0])
+    v = len(vocab) if not isinstance(vocab, int) else vocab
+    if n_docs == 0:
+        raise ValueError("cannot build a BM25 index over zero documents")
+    term_ids = np.asarray(term_ids)
+    doc_ids = np.asarray(doc_ids)
+    if doc_ids.size and np.any(np.diff(doc_ids) < 0):
+        order = np.argsort(doc_ids, kind='stable')
+        term_ids, doc_ids = term_ids[order], doc_ids[order]
+    doc_off = np.zeros(n_docs + 1, np.int64)
+    np.cumsum(np.bincount(doc_ids, minlength=n_docs), out=doc_off[1:])
+    dev = torch.device(device)
+    term_d = torch.from_numpy(np.ascontiguousarray(term_ids, np.int32)).to(dev)
+    indptr_d, rows_d, tf_d = rag_hip.bm25_build_dev(term_d, torch.from_numpy(doc_off).to(dev), v)
+    indptr = indptr_d.cpu().numpy()
+    df = np.diff(indptr).astype(np.int64)
+    total_len = int(doc_len.sum())
+    n_global = n_docs
+    if global_stats is not None:
+        df = np.asarray(global_stats['df'], np.int64)
+        n_global = int(global_stats['n_docs'])
+        total_len = int(global_stats['total_len'])
+    idf = _idf(df, n_global, v)
+    avgdl = total_len / n_global
+    doc_len64 = np.ascontiguousarray(doc_len, np.int64)
+    impacts = rag_hip.bm25_impacts_dev(rows_d, tf_d, torch.from_numpy(doc_len64).to(dev), avgdl, k1, b)
+    arr = Bm25Arrays(vocab, indptr, rows_d.cpu().numpy().view(np.uint32), tf_d.cpu().numpy().view(np.uint32), idf,
+                     doc_len64, avgdl, k1, b)
+    arr._impacts = impacts.cpu().numpy()
+    return arr
 
 
 class BM25Indexer:
@@ -148,7 +194,8 @@ class BM25Indexer:
                 term_ids[at] = t
                 doc_ids[at] = d
                 at += 1
-        self.bm25 = build_arrays(term_ids, doc_ids, doc_len, vocab, self.k1, self.b)
+        # the counting and the sort into term-major order run on the GPU (same arrays as build_arrays)
+        self.bm25 = build_arrays_device(term_ids, doc_ids, doc_len, vocab, self.k1, self.b)
         self._upload()
 
     def _upload(self):

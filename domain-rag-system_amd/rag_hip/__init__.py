@@ -70,6 +70,8 @@ SIGNATURES = {
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'rag_bm25_build_dev': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    'rag_bm25_impacts_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     'rag_enc_mlp_profile': (_i32, [_i32]),
     'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -296,6 +298,33 @@ class DenseIndex:
         check(lib().rag_dense_rescore_dev(self._h, _ptr(queries, torch.float32), b, _ptr(cand_rows, torch.int64), m,
                                           _ptr(out), _stream()), 'rag_dense_rescore_dev')
         return out
+
+
+def bm25_build_dev(term, doc_off, vocab):
+    """Tokenised documents on the device -> term-major CSR on the device (rag_bm25_build_dev).
+    term int32 [n_tokens] (document-major, negative ids ignored), doc_off int64 [n_docs+1];
+    returns (indptr int64 [vocab+1], rows uint32-as-int32-bits [nnz], tf [nnz]) as torch tensors."""
+    import torch
+    n_tokens, n_docs = int(term.shape[0]), int(doc_off.shape[0]) - 1
+    indptr = torch.empty((int(vocab) + 1,), dtype=torch.int64, device=term.device)
+    rows = torch.empty((max(n_tokens, 1),), dtype=torch.int32, device=term.device)
+    tf = torch.empty((max(n_tokens, 1),), dtype=torch.int32, device=term.device)
+    nnz = _i64(0)
+    check(lib().rag_bm25_build_dev(_ptr(term, torch.int32), n_tokens, _ptr(doc_off, torch.int64), n_docs, int(vocab),
+                                   n_tokens, _ptr(indptr), _ptr(rows), _ptr(tf), C.byref(nnz), _stream()),
+          'rag_bm25_build_dev')
+    return indptr, rows[:nnz.value], tf[:nnz.value]
+
+
+def bm25_impacts_dev(rows, tf, doc_len, avgdl, k1, b):
+    """fp64 impact of every posting on the device (rag_bm25_impacts_dev); rows / tf as returned by
+    bm25_build_dev, doc_len int64 [n_docs]."""
+    import torch
+    out = torch.empty((int(rows.shape[0]),), dtype=torch.float64, device=rows.device)
+    check(lib().rag_bm25_impacts_dev(_ptr(rows, torch.int32), _ptr(tf, torch.int32), int(rows.shape[0]),
+                                     _ptr(doc_len, torch.int64), int(doc_len.shape[0]), float(avgdl), float(k1), float(b),
+                                     _ptr(out), _stream()), 'rag_bm25_impacts_dev')
+    return out
 
 
 class Bm25Index:

@@ -126,6 +126,23 @@ int rag_bm25_create(const int64_t* indptr, const uint32_t* rows, const double* i
                     const double* idf, int64_t n_docs, int64_t vocab, int32_t mem_kind,
                     int64_t row_base, rag_bm25_t* out);
 int rag_bm25_destroy(rag_bm25_t h);
+/* Index build on the device (the counting that rank_bm25's BM25Okapi constructor does behind
+ * BM25Indexer.index_chunks, reference src/indexing/bm25_indexer.py:92-106): tokenised documents
+ * -> term-major CSR.  d_term[n_tokens] holds the term ids document after document (negative =
+ * token to ignore), d_doc_off[n_docs+1] the token offsets.  Writes d_indptr[vocab+1] and, for
+ * every (term, document) pair that occurs, d_rows / d_tf (rows ascending inside a term);
+ * *out_nnz = number of pairs, which must fit `capacity` (n_tokens always does; RAG_ELIMIT with
+ * *out_nnz set otherwise).  Integer work: identical to counting on the host.  Returns after the
+ * stream has finished (it allocates and frees its scratch).                              */
+int rag_bm25_build_dev(const int32_t* d_term, int64_t n_tokens, const int64_t* d_doc_off,
+                       int64_t n_docs, int64_t vocab, int64_t capacity, int64_t* d_indptr,
+                       uint32_t* d_rows, uint32_t* d_tf, int64_t* out_nnz, void* stream);
+/* impact[i] = tf (k1+1) / (tf + k1 (1 - b + b doc_len[row] / avgdl)) in fp64, every operation
+ * rounded on its own in the operand order of rank_bm25's get_scores expression, so a posting's
+ * impact is the value the reference multiplies by idf.                                   */
+int rag_bm25_impacts_dev(const uint32_t* d_rows, const uint32_t* d_tf, int64_t nnz,
+                         const int64_t* d_doc_len, int64_t n_docs, double avgdl, double k1, double b,
+                         double* d_impact, void* stream);
 int64_t rag_bm25_docs(rag_bm25_t h);
 
 /* qterms: term ids of all queries back to back (-1 = out of vocabulary, ignored);

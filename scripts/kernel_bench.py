@@ -26,7 +26,7 @@ def main():
     ap.add_argument('--k', type=int, default=100)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--vocab', type=int, default=200_000)
-    ap.add_argument('--stage', default='all', choices=['dense', 'bm25', 'all'])
+    ap.add_argument('--stage', default='all', choices=['dense', 'bm25', 'build', 'all'])
     args = ap.parse_args()
     import rag_hip
     from tests import synth
@@ -79,6 +79,37 @@ def main():
         print(f'bm25: docs={args.rows} batch={args.batch} k={args.k} {ms:.3f} ms/search, postings/query='
               f'{postings / args.batch:.0f}, algorithmic {12.0 * postings / ms / 1e6:.1f} GB/s, '
               f'{args.batch / ms * 1e3:.0f} q/s', flush=True)
+
+    if args.stage == 'build':
+        # index build: host counting (numpy) against the device build of the same token stream
+        from indexing.bm25_indexer import build_arrays
+        term, doc, ln = synth.sparse_corpus(args.rows, args.vocab, seed=2000)
+        t0 = time.perf_counter()
+        ref = build_arrays(term, doc, ln, args.vocab, 1.5, 0.75)
+        ref_imp = ref.impacts()
+        host_s = time.perf_counter() - t0
+        term_d = torch.from_numpy(term.astype(np.int32)).to(dev)
+        off = np.zeros(args.rows + 1, np.int64)
+        np.cumsum(ln, out=off[1:])
+        off_d, ln_d = torch.from_numpy(off).to(dev), torch.from_numpy(ln).to(dev)
+        rag_hip.bm25_build_dev(term_d, off_d, args.vocab)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            ip, rows, tf = rag_hip.bm25_build_dev(term_d, off_d, args.vocab)
+            imp = rag_hip.bm25_impacts_dev(rows, tf, ln_d, ref.avgdl, 1.5, 0.75)
+        torch.cuda.synchronize()
+        dev_s = (time.perf_counter() - t0) / args.iters
+        same = (np.array_equal(ip.cpu().numpy(), ref.indptr) and np.array_equal(rows.cpu().numpy().view(np.uint32), ref.rows)
+                and np.array_equal(tf.cpu().numpy().view(np.uint32), ref.tf)
+                and np.array_equal(imp.cpu().numpy().view(np.uint64), ref_imp.view(np.uint64)))
+        n_tok, nnz = int(term.shape[0]), int(rows.shape[0])
+        # algorithmic bytes: tokens read twice (4 B), the posting stream written and sorted once
+        # (12 B out + 12 B in), rows / tf / impacts written (16 B)
+        gb = (8.0 * n_tok + 40.0 * nnz) / 1e9
+        print(f'build: docs={args.rows} tokens={n_tok} postings={nnz}: host {host_s:.2f} s, device {dev_s * 1e3:.1f} ms '
+              f'({n_tok / dev_s / 1e9:.2f} G tokens/s, {gb / dev_s:.0f} GB/s algorithmic), arrays identical: {same}', flush=True)
+    rag_hip.check_faults()
 
 
 if __name__ == '__main__':

@@ -251,4 +251,10 @@ def install(monkeypatch):
     for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
                  'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev'):
         monkeypatch.setattr(rag_hip, name, globals()[name])
+    # the device-side index build is replaced by the host counting it is tested against on the GPU
+    from indexing import bm25_indexer
+
+    def build_on_host(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=None, device=None):
+        return bm25_indexer.build_arrays(term_ids, doc_ids, doc_len, vocab, k1, b, global_stats=global_stats)
+    monkeypatch.setattr(bm25_indexer, 'build_arrays_device', build_on_host)
     return rag_hip
