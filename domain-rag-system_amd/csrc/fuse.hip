@@ -592,6 +592,61 @@ void rag_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* rag_last_error(void) { return g_err; }
+// ---- payload filters: per-row categorical codes -> row mask ----------------------------------------
+namespace {
+
+constexpr int FILTER_MAX_FIELDS = 8;
+struct FilterParams {
+    const int32_t* codes;              // [n_fields][n_rows]
+    int64_t n_rows;
+    int n_fields;
+    int32_t want[FILTER_MAX_FIELDS];   // code a row must carry in that field; RAG_FILTER_ANY = unconstrained
+    uint8_t* mask;
+};
+
+// mask[row] = 1 iff every constrained field of the row carries the wanted code.  Four rows per thread:
+// the constrained columns are read as 16-byte pieces, unconstrained ones not at all.
+__global__ void filter_mask_kernel(FilterParams p) {
+    const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (r0 >= p.n_rows) return;
+    bool keep[4] = {true, true, true, true};
+    const bool whole = r0 + 4 <= p.n_rows && (p.n_rows & 3) == 0;
+    for (int f = 0; f < p.n_fields; ++f) {
+        if (p.want[f] == RAG_FILTER_ANY) continue;
+        const int32_t* col = p.codes + (int64_t)f * p.n_rows;
+        if (whole) {
+            const int4 c = *reinterpret_cast<const int4*>(col + r0);
+            keep[0] = keep[0] && c.x == p.want[f];
+            keep[1] = keep[1] && c.y == p.want[f];
+            keep[2] = keep[2] && c.z == p.want[f];
+            keep[3] = keep[3] && c.w == p.want[f];
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (r0 + j < p.n_rows) keep[j] = keep[j] && col[r0 + j] == p.want[f];
+        }
+    }
+    for (int j = 0; j < 4; ++j)
+        if (r0 + j < p.n_rows) p.mask[r0 + j] = keep[j] ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int rag_filter_mask_dev(const int32_t* d_codes, int32_t n_fields, int64_t n_rows, const int32_t* want,
+                                   uint8_t* d_mask, void* stream) {
+    RAG_REQUIRE(n_fields >= 0 && n_fields <= FILTER_MAX_FIELDS, RAG_ELIMIT, "rag_filter_mask: at most %d fields (got %d)",
+                FILTER_MAX_FIELDS, n_fields);
+    RAG_REQUIRE(n_rows >= 0, RAG_EINVAL, "rag_filter_mask: negative row count");
+    if (n_rows == 0) return RAG_OK;
+    RAG_REQUIRE(d_mask && (n_fields == 0 || (d_codes && want)), RAG_EINVAL, "rag_filter_mask: null pointer");
+    FilterParams p;
+    p.codes = d_codes; p.n_rows = n_rows; p.n_fields = n_fields; p.mask = d_mask;
+    for (int f = 0; f < FILTER_MAX_FIELDS; ++f) p.want[f] = f < n_fields ? want[f] : RAG_FILTER_ANY;
+    hipLaunchKernelGGL(filter_mask_kernel, dim3((unsigned)ceil_div64(ceil_div64(n_rows, 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 extern "C" int rag_version(void) { return 101; }
 
 // one fault word per device, allocated on first use and kept for the life of the process

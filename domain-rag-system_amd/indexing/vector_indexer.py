@@ -70,6 +70,7 @@ class VectorIndexer:
         self._index = None                  # rag_hip.DenseIndex
         self._payloads = []
         self._canon = None
+        self._code_cols, self._row_filter = {}, None   # per-key categorical codes for device-side filters
         self._created = False
 
     # ---- store management ------------------------------------------------------------
@@ -80,6 +81,7 @@ class VectorIndexer:
         if self._index is not None:
             self._index.close()
         self._index, self._payloads, self._canon = None, [], None
+        self._code_cols, self._row_filter = {}, None
 
     def create_collection(self, force_recreate: bool = True):
         d = self._dir()
@@ -113,6 +115,7 @@ class VectorIndexer:
         rows = np.fromfile(d / 'embeddings.f32', dtype=np.float32).reshape(n, dim)
         with open(d / 'payload.jsonl', 'r', encoding='utf-8') as f:
             self._payloads = [json.loads(line) for line in f]
+        self._code_cols, self._row_filter = {}, None
         self._canon = np.fromfile(d / 'canon.u32', dtype=np.uint32)
         self.distance_metric = meta.get('distance_metric', self.distance_metric)
         self._index = rag_hip.DenseIndex(rows, metric=self.distance_metric)
@@ -147,6 +150,7 @@ class VectorIndexer:
             rows = (rows / np.where(norm == 0, np.float32(1), norm)).astype(np.float32)
         self._drop()
         self._payloads = list(payloads)
+        self._code_cols, self._row_filter = {}, None
         self._canon = canonical_rows([p['chunk_id'] for p in payloads])
         self._index = rag_hip.DenseIndex(rows, metric=self.distance_metric)
         d = self._dir()
@@ -164,6 +168,7 @@ class VectorIndexer:
 
     # ---- search ----------------------------------------------------------------------
     def row_mask(self, filters: Dict):
+        """Host evaluation of the payload filter (every ``key == value`` must hold): one byte per row."""
         if not filters:
             return None
         mask = np.ones(len(self._payloads), np.uint8)
@@ -172,6 +177,53 @@ class VectorIndexer:
                 if mask[i] and _lookup(p, key) != value:
                     mask[i] = 0
         return mask
+
+    def _code_column(self, key):
+        """(value -> code, int32 code per row) of one payload key, built on first use; None when
+        the key's values cannot be dictionary keys (the filter then runs on the host)."""
+        if key not in self._code_cols:
+            table, col = {}, np.empty(len(self._payloads), np.int32)
+            try:
+                for i, p in enumerate(self._payloads):
+                    v = _lookup(p, key)
+                    if v is _MISSING:
+                        col[i] = rag_hip.FILTER_MISSING
+                    elif v != v:                       # NaN equals nothing, itself included
+                        col[i] = rag_hip.FILTER_MISSING
+                    else:
+                        col[i] = table.setdefault(v, len(table))
+                self._code_cols[key] = (table, col)
+            except TypeError:
+                self._code_cols[key] = None
+            self._row_filter = None
+        return self._code_cols[key]
+
+    def row_mask_dev(self, filters: Dict):
+        """The same filter evaluated on the device from per-row categorical codes
+        (rag_filter_mask_dev); a uint8 tensor on the index's device, or None without filters."""
+        import torch
+        if not filters:
+            return None
+        want = {}
+        for key, value in filters.items():
+            col = self._code_column(key)
+            try:
+                want[key] = rag_hip.FILTER_NONE if col is None or value != value else col[0].get(value, rag_hip.FILTER_NONE)
+            except TypeError:
+                col = None
+            if col is None:                            # unhashable values: evaluate on the host
+                dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+                return torch.from_numpy(self.row_mask(filters)).to(dev)
+        if self._row_filter is None or any(k not in self._row_filter.keys for k in want):
+            keys = [k for k, v in self._code_cols.items() if v is not None]
+            keys = [k for k in keys if k in want] + [k for k in keys if k not in want]
+            keys = keys[:rag_hip.RowFilter.MAX_FIELDS]
+            if any(k not in keys for k in want):
+                dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+                return torch.from_numpy(self.row_mask(filters)).to(dev)
+            dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+            self._row_filter = rag_hip.RowFilter({k: self._code_cols[k][1] for k in keys}, device=dev)
+        return self._row_filter.mask_dev(want)
 
     def prepare_queries(self, vectors: np.ndarray) -> np.ndarray:
         q = np.ascontiguousarray(vectors, dtype=np.float32)
@@ -185,7 +237,13 @@ class VectorIndexer:
         if not self._attach():
             raise ValueError(f"Collection {self.collection_name} not found")
         k = min(int(k), rag_hip.MAX_K)
-        return self._index.search(self.prepare_queries(query_vectors), k, row_mask=self.row_mask(filters))
+        if not filters:
+            return self._index.search(self.prepare_queries(query_vectors), k)
+        import torch
+        mask = self.row_mask_dev(filters)
+        q = torch.from_numpy(self.prepare_queries(query_vectors)).to(mask.device)
+        score, row, cnt = self._index.search_dev(q, k, row_mask=mask)
+        return score.cpu().numpy(), row.cpu().numpy(), cnt.cpu().numpy()
 
     def format_hit(self, row: int, score: float) -> Dict:
         p = self._payloads[row]

@@ -70,6 +70,7 @@ SIGNATURES = {
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'rag_filter_mask_dev': (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
     'rag_bm25_build_dev': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     'rag_bm25_impacts_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     'rag_enc_mlp_profile': (_i32, [_i32]),
@@ -298,6 +299,42 @@ class DenseIndex:
         check(lib().rag_dense_rescore_dev(self._h, _ptr(queries, torch.float32), b, _ptr(cand_rows, torch.int64), m,
                                           _ptr(out), _stream()), 'rag_dense_rescore_dev')
         return out
+
+
+FILTER_ANY, FILTER_NONE, FILTER_MISSING = -1, -2, -3
+
+
+class RowFilter:
+    """Per-row categorical codes resident on the device; ``mask_dev`` turns an exact-match filter
+    into the row mask the dense search takes (rag_filter_mask_dev).  ``columns`` maps a key to an
+    int32 code per row (>= 0; FILTER_MISSING for rows without the key)."""
+
+    MAX_FIELDS = 8
+
+    def __init__(self, columns, device='cuda'):
+        import torch
+        self.keys = list(columns)
+        if len(self.keys) > self.MAX_FIELDS:
+            raise ValueError(f"at most {self.MAX_FIELDS} filterable keys")
+        cols = [np.ascontiguousarray(columns[k], np.int32) for k in self.keys]
+        self.n_rows = int(cols[0].shape[0]) if cols else 0
+        if any(c.shape != (self.n_rows,) for c in cols):
+            raise ValueError("every code column needs one entry per row")
+        stacked = np.stack(cols) if cols else np.zeros((0, 0), np.int32)
+        self.codes = torch.from_numpy(stacked).to(device)
+
+    def mask_dev(self, want):
+        """want: key -> wanted code (FILTER_NONE when the value occurs in no row); keys left out are
+        unconstrained.  Returns a uint8 [n_rows] tensor on the device."""
+        import torch
+        unknown = [k for k in want if k not in self.keys]
+        if unknown:
+            raise KeyError(f"no code column for {unknown}")
+        w = np.array([int(want.get(k, FILTER_ANY)) for k in self.keys], np.int32)
+        mask = torch.empty((self.n_rows,), dtype=torch.uint8, device=self.codes.device)
+        check(lib().rag_filter_mask_dev(_ptr(self.codes, torch.int32) if self.keys else None, len(self.keys), self.n_rows,
+                                        w.ctypes.data if self.keys else None, _ptr(mask), _stream()), 'rag_filter_mask_dev')
+        return mask
 
 
 def bm25_build_dev(term, doc_off, vocab):

@@ -107,6 +107,17 @@ int rag_dense_search(rag_dense_t h, const float* queries, int32_t n_queries, int
                      const uint8_t* row_mask, float* out_score, int64_t* out_row,
                      int32_t* out_count);
 
+/* Payload filter on the device: the exact-match filter of VectorIndexer.search (reference
+ * src/indexing/vector_indexer.py:185-196: every key == value must hold) over per-row categorical
+ * codes.  d_codes[n_fields][n_rows] int32 (one column per filterable key; the host assigns a code
+ * per distinct value, a negative code to rows that lack the key); want[n_fields] on the host: the
+ * code a row must carry, RAG_FILTER_ANY for an unconstrained key, RAG_FILTER_NONE when the value
+ * occurs in no row (then no row passes).  Writes d_mask[n_rows] (1 = keep), the row_mask argument
+ * of rag_dense_search[_dev].  At most 8 fields.                                          */
+#define RAG_FILTER_ANY (-1)
+#define RAG_FILTER_NONE (-2)
+int rag_filter_mask_dev(const int32_t* d_codes, int32_t n_fields, int64_t n_rows, const int32_t* want,
+                        uint8_t* d_mask, void* stream);
 /* Exact fp32 scores of given candidate rows (GLOBAL ids, -1 = skip -> score 0):
  * out[q*m+j] = score(query q, row cand[q*m+j]).  Serves SimpleSimilarityReranker
  * (reference src/reranker/rerank.py:60-68) from the resident embeddings.          */

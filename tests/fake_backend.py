@@ -245,11 +245,32 @@ def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair
     return ids, types, mask
 
 
+FILTER_ANY, FILTER_NONE, FILTER_MISSING = -1, -2, -3
+
+
+class RowFilter:
+    """Host double of rag_hip.RowFilter: the same mask from the same code columns."""
+    MAX_FIELDS = 8
+
+    def __init__(self, columns, device='cpu'):
+        self.keys = list(columns)
+        self.cols = {k: np.asarray(v, np.int32) for k, v in columns.items()}
+        self.n_rows = len(next(iter(self.cols.values()))) if self.cols else 0
+
+    def mask_dev(self, want):
+        mask = np.ones(self.n_rows, np.uint8)
+        for k, w in want.items():
+            if w != FILTER_ANY:
+                mask &= (self.cols[k] == w).astype(np.uint8)
+        return torch.from_numpy(mask)
+
+
 def install(monkeypatch):
     """Replace the GPU entry points of the imported ``rag_hip`` module with the doubles."""
     import rag_hip
     for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
-                 'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev'):
+                 'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev',
+                 'RowFilter'):
         monkeypatch.setattr(rag_hip, name, globals()[name])
     # the device-side index build is replaced by the host counting it is tested against on the GPU
     from indexing import bm25_indexer

@@ -84,3 +84,34 @@ def test_index_built_on_device_searches_like_the_host_built_one():
     sa, ra, ca = a.search(queries, 20)
     sb, rb, cb = b.search(queries, 20)
     assert np.array_equal(ca, cb) and np.array_equal(ra, rb) and np.array_equal(sa.view(np.uint64), sb.view(np.uint64))
+
+
+def test_filter_mask_matches_host_evaluation():
+    """Payload filters evaluated on the device from categorical codes against the host loop."""
+    import rag_hip
+    from indexing.vector_indexer import VectorIndexer
+
+    class _Emb:
+        embedding_dim, model_name = 8, 'none'
+    rng = np.random.default_rng(3)
+    n = 5003
+    payloads = []
+    for i in range(n):
+        p = {'chunk_id': f'c{i}', 'doc_id': f'd{i // 7}', 'source': ['pubmed', 'openfda', 'kaggle'][int(rng.integers(0, 3))],
+             'chunk_type': ['abstract', 'title'][i % 2], 'text': '', 'metadata': {'year': int(rng.integers(2000, 2004))}}
+        if i % 11 == 0:
+            del p['metadata']['year']
+        payloads.append(p)
+    vi = VectorIndexer(embedder=_Emb(), use_in_memory=True)
+    vi.add_points(rng.standard_normal((n, 8)).astype(np.float32), payloads)
+    for filt in ({'source': 'openfda'}, {'source': 'pubmed', 'chunk_type': 'title'}, {'metadata.year': 2002},
+                 {'source': 'nowhere'}, {'doc_id': 'd100', 'chunk_type': 'abstract'}, {'metadata.year': 2001, 'source': 'kaggle'},
+                 {'no_such_key': 1}, {'metadata': {'year': 2001}}):
+        want = vi.row_mask(filt)
+        got = vi.row_mask_dev(filt).cpu().numpy()
+        assert np.array_equal(got, want), filt
+    # and through the search: filtered top-k equals a search with the host-built mask
+    q = rng.standard_normal((3, 8)).astype(np.float32)
+    s1, r1, c1 = vi.search_rows(q, 10, {'source': 'pubmed', 'chunk_type': 'title'})
+    s2, r2, c2 = vi._index.search(vi.prepare_queries(q), 10, row_mask=vi.row_mask({'source': 'pubmed', 'chunk_type': 'title'}))
+    assert np.array_equal(r1, r2) and np.array_equal(c1, c2) and np.array_equal(s1, s2)
