@@ -496,6 +496,124 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 #endif
 }
 
+
+// ---- Y = X W^T + bias for 384-wide inputs (the q|k|v projection) ------------------------------------
+// The first product of the block above, on its own: a wave owns 32 tokens whose X fragments stay in
+// registers, W streams through LDS in images of 32 output features (the W1 image: swizzled, rows in the
+// swapped order, so registers 8t..8t+7 of the accumulator are features 16t + 8h + 0..7 and the output
+// is stored in 16-byte pieces).  24 MFMAs per image alternate between two accumulators; that keeps an
+// accumulator's MFMAs two apart, half the matrix rate for one wave — but this kernel needs few
+// registers, so TWO workgroups share a CU and the second wave of a SIMD fills the gaps (and the
+// barrier, the weight loads and the stores of the other).  The stores of an image are issued at the
+// start of the next one, so the wait that retires the weight loads does not wait for fresh stores.
+constexpr int LN_PF = 4;
+
+struct LinearParams {
+    const bf16* x;        // [M][384]
+    const bf16* w;        // [N][384]
+    const bf16* bias;     // [N]
+    bf16* y;              // [M][N]
+    int64_t M;
+    int N;
+};
+
+__global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // W images [2][32][48 x 16 B], bias fp32 [N]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t tok = (int64_t)blockIdx.x * ML_BM + wave * 32 + r;
+    const int64_t tok_ld = min(tok, p.M - 1);
+    const bool live = tok < p.M;
+    const int n_img = p.N / ML_C;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    uint32_t off1[ML_W_DMAS];
+#pragma unroll
+    for (int i = 0; i < ML_W_DMAS; ++i) {
+        const int L = 64 * (wave + 4 * i) + lane;
+        const int q = L / 48, j1 = (L % 48) ^ (q & 15);
+        const int unit = (q & ~12) | ((q & 4) << 1) | ((q & 8) >> 1);
+        off1[i] = (uint32_t)((unit * ML_HID + j1 * 8) * 2);
+    }
+    auto dma = [&](int c, int buf, int i) {
+        lds_dma16(lds0 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), p.w + (size_t)c * ML_C * ML_HID, off1[i]);
+    };
+#pragma unroll
+    for (int i = 0; i < ML_W_DMAS; ++i) dma(0, 0, i);
+    for (int i = tid; i < p.N; i += ML_NT) *reinterpret_cast<float*>(smem + 2 * ML_W_BYTES + 4 * i) = (float)p.bias[i];
+
+    bf16x8 xf[ML_KS];
+    {
+        const bf16* xrow = p.x + tok_ld * ML_HID + 8 * h;
+#pragma unroll
+        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
+    }
+    uint32_t l1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l1[u] = lds0 + r * (ML_HID * 2) + 16 * ((2 * u + h) ^ (r & 15));
+    const unsigned char* bias_s = smem + 2 * ML_W_BYTES + 32 * h;
+    bf16* yrow = p.y + tok * p.N + 8 * h;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8 out0, out1;                                        // the previous image's results, stored one image later
+    auto image = [&](int c, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
+        if (c > 0 && live) {
+            *reinterpret_cast<bf16x8*>(yrow + (c - 1) * ML_C) = out0;
+            *reinterpret_cast<bf16x8*>(yrow + (c - 1) * ML_C + 16) = out1;
+        }
+        const int cn = min(c + 1, n_img - 1);
+        u32x4 q[LN_PF + 1];
+        f32x16 ae, ao;
+        auto issue = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q[S % (LN_PF + 1)], l1[S & 7]);
+        };
+        auto step = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (S < ML_W_DMAS) dma(cn, BUF ^ 1, S);
+            if constexpr (S + LN_PF < ML_KS) issue(std::integral_constant<int, S + LN_PF>{});
+            constexpr int newer = ML_KS - 1 - S < LN_PF ? ML_KS - 1 - S : LN_PF;
+            lds_wait<newer>(q[S % (LN_PF + 1)]);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, q[S % (LN_PF + 1)]);
+            if constexpr (S == 0)
+                ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0], zero16, 0, 0, 0);
+            else if constexpr (S == 1)
+                ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1], zero16, 0, 0, 0);
+            else if constexpr (S % 2 == 0)
+                ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[S], ae, 0, 0, 0);
+            else
+                ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[S], ao, 0, 0, 0);
+        };
+        unrolled(std::make_integer_sequence<int, LN_PF>{}, issue);
+        unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
+        // registers 8t..8t+7 are features 32c + 16t + 8h + 0..7
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4));
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4) + 16);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4) + 64);
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4) + 80);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            out0[j] = (bf16)(ae[j] + ao[j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
+            out1[j] = (bf16)(ae[8 + j] + ao[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int c = 0; c < n_img; c += 2) {
+        image(c, std::integral_constant<int, 0>{});
+        if (c + 1 < n_img) image(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (live) {
+        *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C) = out0;
+        *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C + 16) = out1;
+    }
+}
+
 }  // namespace
 
 #if ML_STAMPS
@@ -617,5 +735,29 @@ extern "C" int rag_enc_mlp_profile_read(float* out_ms, int64_t* out_rows, int32_
     }
     *out_n = n;
     g_prof.n = 0;
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t n,
+                                     int32_t dtype, void* d_y, void* stream_) {
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_linear384: bf16 only");
+    RAG_REQUIRE(n >= ML_C && n % ML_C == 0 && n <= 4 * ML_MAX_I, RAG_ELIMIT,
+                "rag_enc_linear384: the output width must be a multiple of %d (got %d)", ML_C, n);
+    RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_linear384: negative row count");
+    if (m == 0) return RAG_OK;
+    RAG_REQUIRE(d_x && d_w && d_bias && d_y, RAG_EINVAL, "rag_enc_linear384: null pointer");
+    RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_linear384: y must not alias x");
+    RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear384: too many rows");
+    const size_t lds_bytes = 2 * (size_t)ML_W_BYTES + 4 * (size_t)n;
+    RAG_REQUIRE(lds_bytes <= 80 * 1024, RAG_ELIMIT, "rag_enc_linear384: output width %d too large", n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    LinearParams p;
+    p.x = (const bf16*)d_x; p.w = (const bf16*)d_w; p.bias = (const bf16*)d_bias; p.y = (bf16*)d_y; p.M = m; p.N = n;
+    hipLaunchKernelGGL(linear384_kernel, dim3((unsigned)ceil_div64(m, ML_BM)), dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+    RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

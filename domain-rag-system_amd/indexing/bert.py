@@ -104,6 +104,7 @@ class BertEncoder(nn.Module):
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
+        self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
         self.fused_tail = False      # ... and the attention-output projection + LayerNorm in the same kernel
 
@@ -164,15 +165,15 @@ class BertEncoder(nn.Module):
         x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
-        lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else (lambda m, v: m(v))
+        lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
         for li, l in enumerate(self.layers):
             if first_token_only and li == last and x.dtype == torch.bfloat16:
-                ctx = rag_hip.enc_attention_packed_first_dev(l.qkv(x), cu_seqlens, max_seq_len, l.heads)
+                ctx = rag_hip.enc_attention_packed_first_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
                 x = x[cu_seqlens[:-1].long()]
                 if self._layer_tail_fused(l, x):
                     return self._layer_tail(l, ctx, x)
-                x = rag_hip.enc_add_layernorm_dev(l.attn_out(ctx), x, l.attn_norm.weight, l.attn_norm.bias,
+                x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
                                                   l.attn_norm.eps)
                 return self._feed_forward(l, x, lin)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
@@ -189,6 +190,13 @@ class BertEncoder(nn.Module):
                                                   l.attn_norm.eps)
             x = self._feed_forward(l, x, lin)
         return x
+
+    def _linear(self, module, x):
+        """nn.Linear; 384-wide bfloat16 inputs go through rag_enc_linear384_dev."""
+        import rag_hip
+        if self.native_linear and x.dim() == 2 and rag_hip.enc_linear384_supported(x, module.weight):
+            return rag_hip.enc_linear384_dev(x.contiguous(), module.weight, module.bias)
+        return module(x)
 
     def _layer_tail_fused(self, l, x):
         import rag_hip

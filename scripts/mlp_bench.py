@@ -64,6 +64,19 @@ def main():
             b.record()
             torch.cuda.synchronize()
             print(f'{name}: {a.elapsed_time(b) / args.iters:.3f} ms', flush=True)
+    lq = torch.nn.Linear(384, 1152, device=dev, dtype=bf)
+    with torch.no_grad():
+        for name, fn in (('q|k|v projection, library GEMM', lambda: lq(x)),
+                         ('q|k|v projection, rag_enc_linear384_dev', lambda: rag_hip.enc_linear384_dev(x, lq.weight, lq.bias))):
+            fn()
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(args.iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / args.iters
+            print(f'{name}: {ms:.3f} ms ({2.0 * args.tokens * 384 * 1152 / ms / 1e9:.0f} TFLOP/s)', flush=True)
     rag_hip.check_faults()
     import ctypes
     L = rag_hip.lib()

@@ -75,6 +75,22 @@ def test_attention_output_and_mlp_block_matches_exact(m, inter):
     assert float(err.mean()) <= float((yu.double() - ref).abs().mean()) * 1.1 + 1e-4
 
 
+@pytest.mark.parametrize('m,n', [(1000, 1152), (128, 1152), (1, 32), (129, 64), (4097, 1152), (77, 384)])
+def test_linear384_matches_exact(m, n):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(3 * m + n)
+    x = torch.randn((m, 384), generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn((n, 384), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    b = (torch.randn((n,), generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    y = rag_hip.enc_linear384_dev(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    # bf16 output of an fp32 accumulation: half an ulp of bf16 relative, plus accumulation noise
+    assert float(((y.double() - ref).abs() / (ref.abs() + 1.0)).max()) < 6e-3
+    lib_y = (x @ w.t() + b)
+    assert float((y.double() - ref).abs().mean()) <= float((lib_y.double() - ref).abs().mean()) * 1.05
+
+
 def test_mlp_rows_are_independent():
     """A row's result does not depend on which workgroup or lane computes it."""
     import rag_hip
