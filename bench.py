@@ -55,6 +55,8 @@ def parse():
                     help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
     ap.add_argument('--ce-fused-attn-out', action='store_true',
                     help='tuning aid: attention-output projection + LayerNorm inside the feed-forward kernel')
+    ap.add_argument('--ce-fused-attn-norm', action='store_true',
+                    help='tuning aid: residual + LayerNorm after the output projection inside rag_enc_linear384_dev')
     ap.add_argument('--ce-library-linear', action='store_true',
                     help='tuning aid: q|k|v and output projections as library GEMMs instead of rag_enc_linear384_dev')
     ap.add_argument('--ce-library-mlp', action='store_true',
@@ -257,6 +259,7 @@ def main():
     ce.bert.fused_linear = bool(args.ce_fused_linear)
     ce.bert.fused_mlp = not args.ce_library_mlp
     ce.bert.native_linear = not args.ce_library_linear
+    ce.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
     ce.bert.fused_tail = bool(args.ce_fused_attn_out)
     searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,

@@ -515,8 +515,17 @@ struct LinearParams {
     bf16* y;              // [M][N]
     int64_t M;
     int N;
+    // LN kernels (N == 384): y = LayerNorm(x W^T + bias + residual) * gamma + beta
+    const bf16* residual; // [M][384]
+    const bf16* gamma;    // [384]
+    const bf16* beta;     // [384]
+    float eps;
 };
 
+// LN: the sum is rounded to bf16 and stored image by image while the row statistics are gathered
+// from the rounded values; a second pass over the wave's own rows (just written, still in cache)
+// normalises them in place.
+template <bool LN>
 __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // W images [2][32][48 x 16 B], bias fp32 [N]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -554,6 +563,8 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
     for (int u = 0; u < 8; ++u) l1[u] = lds0 + r * (ML_HID * 2) + 16 * ((2 * u + h) ^ (r & 15));
     const unsigned char* bias_s = smem + 2 * ML_W_BYTES + 32 * h;
     bf16* yrow = p.y + tok * p.N + 8 * h;
+    const bf16* rrow = LN ? p.residual + tok_ld * ML_HID + 8 * h : nullptr;
+    float rsum = 0.f, rsq = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -567,6 +578,11 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
             *reinterpret_cast<bf16x8*>(yrow + (c - 1) * ML_C + 16) = out1;
         }
         const int cn = min(c + 1, n_img - 1);
+        bf16x8 res0, res1;
+        if constexpr (LN) {
+            res0 = *reinterpret_cast<const bf16x8*>(rrow + c * ML_C);
+            res1 = *reinterpret_cast<const bf16x8*>(rrow + c * ML_C + 16);
+        }
         u32x4 q[LN_PF + 1];
         f32x16 ae, ao;
         auto issue = [&](auto s_c) {
@@ -598,8 +614,19 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
         const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4) + 80);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            out0[j] = (bf16)(ae[j] + ao[j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
-            out1[j] = (bf16)(ae[8 + j] + ao[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]));
+            float v0 = ae[j] + ao[j] + (j < 4 ? b0[j & 3] : b1[j & 3]);
+            float v1 = ae[8 + j] + ao[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]);
+            if constexpr (LN) {
+                v0 += (float)res0[j];
+                v1 += (float)res1[j];
+            }
+            out0[j] = (bf16)v0;
+            out1[j] = (bf16)v1;
+            if constexpr (LN) {
+                const float r0 = (float)out0[j], r1 = (float)out1[j];
+                rsum += r0 + r1;
+                rsq += r0 * r0 + r1 * r1;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -611,6 +638,26 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
     if (live) {
         *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C) = out0;
         *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C + 16) = out1;
+    }
+    if constexpr (LN) {
+        // a token's 384 values are split between this lane and its partner in the other half-wave
+        rsum += __shfl_xor(rsum, 32, 64);
+        rsq += __shfl_xor(rsq, 32, 64);
+        const float mean = rsum / (float)ML_HID;
+        const float var = fmaxf(rsq / (float)ML_HID - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        if (live) {
+#pragma unroll 4
+            for (int t = 0; t < ML_KS; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(yrow + 16 * t);
+                const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(p.gamma + 16 * t + 8 * h);
+                const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(p.beta + 16 * t + 8 * h);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)v[j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+                *reinterpret_cast<bf16x8*>(yrow + 16 * t) = o;
+            }
+        }
     }
 }
 
@@ -739,6 +786,7 @@ extern "C" int rag_enc_mlp_profile_read(float* out_ms, int64_t* out_rows, int32_
 }
 
 extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t n,
+                                     const void* d_residual, const void* d_gamma, const void* d_beta, float eps,
                                      int32_t dtype, void* d_y, void* stream_) {
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_linear384: bf16 only");
     RAG_REQUIRE(n >= ML_C && n % ML_C == 0 && n <= 4 * ML_MAX_I, RAG_ELIMIT,
@@ -747,17 +795,25 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_w && d_bias && d_y, RAG_EINVAL, "rag_enc_linear384: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_linear384: y must not alias x");
+    RAG_REQUIRE(d_residual == nullptr || (n == ML_HID && d_gamma && d_beta), RAG_EINVAL,
+                "rag_enc_linear384: the residual + LayerNorm tail needs n == %d, gamma and beta", ML_HID);
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear384: too many rows");
     const size_t lds_bytes = 2 * (size_t)ML_W_BYTES + 4 * (size_t)n;
     RAG_REQUIRE(lds_bytes <= 80 * 1024, RAG_ELIMIT, "rag_enc_linear384: output width %d too large", n);
     static bool attr_set = false;
     if (!attr_set) {
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
-    LinearParams p;
+    LinearParams p = {};
     p.x = (const bf16*)d_x; p.w = (const bf16*)d_w; p.bias = (const bf16*)d_bias; p.y = (bf16*)d_y; p.M = m; p.N = n;
-    hipLaunchKernelGGL(linear384_kernel, dim3((unsigned)ceil_div64(m, ML_BM)), dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+    p.residual = (const bf16*)d_residual; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.eps = eps;
+    const dim3 grid((unsigned)ceil_div64(m, ML_BM));
+    if (d_residual)
+        hipLaunchKernelGGL(linear384_kernel<true>, grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+    else
+        hipLaunchKernelGGL(linear384_kernel<false>, grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

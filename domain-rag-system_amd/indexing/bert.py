@@ -105,6 +105,7 @@ class BertEncoder(nn.Module):
         self._split_cache = {}
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
+        self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
         self.fused_tail = False      # ... and the attention-output projection + LayerNorm in the same kernel
 
@@ -173,8 +174,7 @@ class BertEncoder(nn.Module):
                 x = x[cu_seqlens[:-1].long()]
                 if self._layer_tail_fused(l, x):
                     return self._layer_tail(l, ctx, x)
-                x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
-                                                  l.attn_norm.eps)
+                x = self._attn_output(l, ctx, x, lin)
                 return self._feed_forward(l, x, lin)
             ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
             if self._layer_tail_fused(l, x):
@@ -186,8 +186,7 @@ class BertEncoder(nn.Module):
                                            rag_hip.EPILOGUE_BIAS_RESIDUAL_LAYERNORM, x, l.attn_norm.weight,
                                            l.attn_norm.bias, l.attn_norm.eps)
             else:
-                x = rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
-                                                  l.attn_norm.eps)
+                x = self._attn_output(l, ctx, x, lin)
             x = self._feed_forward(l, x, lin)
         return x
 
@@ -197,6 +196,18 @@ class BertEncoder(nn.Module):
         if self.native_linear and x.dim() == 2 and rag_hip.enc_linear384_supported(x, module.weight):
             return rag_hip.enc_linear384_dev(x.contiguous(), module.weight, module.bias)
         return module(x)
+
+    def _attn_output(self, l, ctx, x, lin):
+        """LayerNorm(x + attention-output projection of ctx): one kernel for 384-wide bfloat16
+        layers (projection with the residual + LayerNorm tail), else GEMM + residual/LayerNorm kernel."""
+        import rag_hip
+        w = l.attn_out.weight
+        if (self.native_linear and self.fused_attn_norm and ctx.dim() == 2 and w.shape[0] == 384
+                and rag_hip.enc_linear384_supported(ctx, w)):
+            return rag_hip.enc_linear384_dev(ctx.contiguous(), w, l.attn_out.bias, x.contiguous(), l.attn_norm.weight,
+                                             l.attn_norm.bias, l.attn_norm.eps)
+        return rag_hip.enc_add_layernorm_dev(lin(l.attn_out, ctx), x, l.attn_norm.weight, l.attn_norm.bias,
+                                             l.attn_norm.eps)
 
     def _layer_tail_fused(self, l, x):
         import rag_hip

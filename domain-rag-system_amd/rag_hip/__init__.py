@@ -73,7 +73,7 @@ SIGNATURES = {
     'rag_filter_mask_dev': (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
     'rag_bm25_build_dev': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     'rag_bm25_impacts_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp]),
-    'rag_enc_linear384_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    'rag_enc_linear384_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_profile': (_i32, [_i32]),
     'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -812,16 +812,21 @@ def enc_linear384_supported(x, weight):
             and weight.shape[1] == 384 and weight.shape[0] % 32 == 0 and weight.shape[0] <= 6144)
 
 
-def enc_linear384_dev(x, weight, bias):
-    """x @ weight.T + bias for 384-wide bf16 inputs (rag_enc_linear384_dev); x [M, 384], weight [N, 384]."""
+def enc_linear384_dev(x, weight, bias, residual=None, gamma=None, beta=None, eps=1e-12):
+    """x @ weight.T + bias for 384-wide bf16 inputs (rag_enc_linear384_dev); x [M, 384], weight [N, 384].
+    With ``residual`` [M, 384] (N == 384): LayerNorm(that + residual) * gamma + beta."""
     import torch
     m, k = x.shape
     n = weight.shape[0]
     if k != 384 or weight.shape[1] != 384 or tuple(bias.shape) != (n,):
         raise ValueError("x must be [M, 384], weight [N, 384] and bias [N]")
+    if residual is not None and (n != 384 or tuple(residual.shape) != (m, 384) or gamma is None or beta is None
+                                 or tuple(gamma.shape) != (384,) or tuple(beta.shape) != (384,)):
+        raise ValueError("the LayerNorm tail needs N == 384, residual [M, 384], gamma [384] and beta [384]")
     y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
     bf = torch.bfloat16
-    check(lib().rag_enc_linear384_dev(_ptr(x, bf), _ptr(weight, bf), _ptr(bias, bf), m, n, DTYPE_BF16, _ptr(y), _stream()),
+    check(lib().rag_enc_linear384_dev(_ptr(x, bf), _ptr(weight, bf), _ptr(bias, bf), m, n, _ptr(residual, bf),
+                                      _ptr(gamma, bf), _ptr(beta, bf), float(eps), DTYPE_BF16, _ptr(y), _stream()),
           'rag_enc_linear384_dev')
     return y
 

@@ -340,9 +340,13 @@ int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_w
                              int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y,
                              void* stream);
 /* y[m][n] = sum_k x[m][k] w[n][k] + bias[n] for 384-wide inputs (bf16, fp32 accumulation): the
- * q|k|v projection of the cross-encoder layers (same reference path as rag_enc_mlp_dev).  x [m][384],
- * w [n][384] as nn.Linear stores it, n a multiple of 32; y must not alias x.              */
+ * q|k|v and attention-output projections of the cross-encoder layers (same reference path as
+ * rag_enc_mlp_dev).  x [m][384], w [n][384] as nn.Linear stores it, n a multiple of 32; y must not
+ * alias x.  With d_residual != NULL (n == 384): y = LayerNorm(that + residual[m]) * gamma + beta,
+ * the sum rounded to bf16 before the statistics as a separate residual + LayerNorm pass over a
+ * bf16 GEMM output would see it; y may alias residual.                                  */
 int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t n,
+                          const void* d_residual, const void* d_gamma, const void* d_beta, float eps,
                           int32_t dtype, void* d_y, void* stream);
 /* Measurement aid (no counterpart in the reference): while enabled, every launch of the
  * feed-forward kernel (rag_enc_mlp_dev, rag_enc_attn_out_mlp_dev) records a HIP event pair on

@@ -91,6 +91,28 @@ def test_linear384_matches_exact(m, n):
     assert float((y.double() - ref).abs().mean()) <= float((lib_y.double() - ref).abs().mean()) * 1.05
 
 
+@pytest.mark.parametrize('m', [1000, 128, 1, 129, 4097])
+def test_linear384_residual_layernorm_tail(m):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(13 * m)
+    bf = torch.bfloat16
+    x = torch.randn((m, 384), generator=g, device=dev).to(bf)
+    res = torch.randn((m, 384), generator=g, device=dev).to(bf)
+    w = (torch.randn((384, 384), generator=g, device=dev) * 0.05).to(bf)
+    b = (torch.randn((384,), generator=g, device=dev) * 0.1).to(bf)
+    gamma = (1 + 0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    beta = (0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    y = rag_hip.enc_linear384_dev(x, w, b, res, gamma, beta, 1e-12)
+    v = x.double() @ w.double().t() + b.double() + res.double()
+    ref = torch.nn.functional.layer_norm(v, (384,), gamma.double(), beta.double(), 1e-12)
+    err = (y.double() - ref).abs()
+    assert float(err.max()) < 5e-2 and float(err.mean()) < 5e-3
+    # the separate route: bf16 GEMM output, then the residual + LayerNorm kernel
+    unf = rag_hip.enc_add_layernorm_dev(rag_hip.enc_linear384_dev(x, w, b), res, gamma, beta, 1e-12)
+    assert float(err.mean()) <= float((unf.double() - ref).abs().mean()) * 1.1 + 1e-4
+
+
 def test_mlp_rows_are_independent():
     """A row's result does not depend on which workgroup or lane computes it."""
     import rag_hip
