@@ -57,6 +57,9 @@ def parse():
                     help='tuning aid: attention-output projection + LayerNorm inside the feed-forward kernel')
     ap.add_argument('--ce-fused-attn-norm', action='store_true',
                     help='tuning aid: residual + LayerNorm after the output projection inside rag_enc_linear384_dev')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='overlap the retrieval half of batch i+1 with the rerank of batch i on a second stream '
+                         '(BatchSearcher.search_many; measured: no gain, the rerank kernels already fill the chip)')
     ap.add_argument('--ce-library-linear', action='store_true',
                     help='tuning aid: q|k|v and output projections as library GEMMs instead of rag_enc_linear384_dev')
     ap.add_argument('--ce-library-mlp', action='store_true',
@@ -277,14 +280,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(queries[i])
+    def as_args(q):
+        return (q['ids'], q['mask'], q['qterms'], q['qoff'], q['n_terms'], q['ce_tok'], q['ce_off'])
+
+    def run(batch_list):
+        # K steps = K batches through the whole path, one after the other; with --pipeline the retrieval half
+        # of batch i+1 overlaps the rerank of batch i on a second stream (all K x both halves inside the timed region)
+        if not args.pipeline:
+            return [step(q) for q in batch_list]
+        return searcher.search_many([as_args(q) for q in batch_list])
+
+    run(queries[:args.warmup])
     barrier()
     dense.profile(True)
     rag_hip.enc_mlp_profile(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(queries[args.warmup + i])
+    out = run(queries[args.warmup:args.warmup + args.steps])[-1]
     barrier()
     dt = time.perf_counter() - t0
     scan_ms = dense.profile_read()
@@ -367,7 +378,8 @@ def main():
                    'rows_per_gpu': args.rows, 'rows_total': n_total, 'dim': args.dim, 'batch': args.batch,
                    'per_list_k': 2 * t, 'fused': t, 'ce_pairs_per_query': t, 'vocab': args.vocab,
                    'embedder': args.embed_arch, 'cross_encoder': args.ce_arch,
-                   'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU'},
+                   'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU',
+                   'batch_pipelining': bool(world == 1 and args.pipeline and args.steps > 1)},
         'stage_ms_per_step': stage_ms,
         'roofline': roofline,
         'roofline_feed_forward': roofline_ff,

@@ -67,6 +67,7 @@ class BatchSearcher:
         self.rank = dist.get_rank() if dist is not None else 0
         self.times = StageTimes()
         self.timing = False
+        self._side_stream = None
 
     # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
     @property
@@ -225,9 +226,9 @@ class BatchSearcher:
             p0 = p1
 
     # ---- whole path ------------------------------------------------------------------
-    def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):
-        """One batch through the whole path.  Returns dict of device tensors:
-        rows [B, top_k] (global), fused_score f64 [B, top_k], rerank_score f32 (if reranked)."""
+    def retrieve(self, embed_ids, embed_mask, qterms, qoff, n_terms):
+        """First half of the path: embed -> dense kNN, BM25 -> fusion.  Returns the fused lists
+        (positions, rows [B, T] global, scores f64, counts) as device tensors."""
         t = self.fetch_k
         k_list = min(2 * t, rag_hip.MAX_K)
         vec = bm = None
@@ -244,7 +245,11 @@ class BatchSearcher:
         if bm is None:
             bm = (torch.zeros((b, 1), dtype=torch.float64, device=dev), torch.full((b, 1), -1, dtype=torch.int64, device=dev),
                   torch.zeros((b,), dtype=torch.int32, device=dev))
-        pos, row, score, cnt = self._timed('fuse', lambda: self.fuse(vec, bm, t))
+        return self._timed('fuse', lambda: self.fuse(vec, bm, t))
+
+    def finish(self, fused, ce_q_tok=None, ce_q_off=None):
+        """Second half: cross-encoder rerank of the fused lists (or the plain cut to top_k)."""
+        pos, row, score, cnt = fused
         out = {'fused_row': row, 'fused_score': score, 'fused_count': cnt}
         if self.cross_encoder is None:
             out.update(rows=row[:, :self.top_k], scores=score[:, :self.top_k], count=torch.clamp(cnt, max=self.top_k))
@@ -255,3 +260,41 @@ class BatchSearcher:
                    scores=torch.gather(score, 1, safe), rerank_score=torch.gather(logits, 1, safe), count=rc,
                    rerank_pos=idx)
         return out
+
+    def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):
+        """One batch through the whole path.  Returns dict of device tensors:
+        rows [B, top_k] (global), fused_score f64 [B, top_k], rerank_score f32 (if reranked)."""
+        return self.finish(self.retrieve(embed_ids, embed_mask, qterms, qoff, n_terms), ce_q_tok, ce_q_off)
+
+    def search_many(self, batches):
+        """Several batches, software-pipelined over two HIP streams: while the cross-encoder
+        reranks batch i on the current stream, the retrieval half of batch i+1 (small kernels
+        that leave most of the chip idle) runs on a side stream.  ``batches`` is a list of
+        argument tuples of ``search``; returns the list of its result dicts.  With more than one
+        rank the batches run one after the other: the retrieval half contains collectives, and
+        one communicator must not be driven from two streams at once."""
+        if self.world > 1 or self.cross_encoder is None or len(batches) < 2 or self.timing:
+            return [self.search(*b) for b in batches]
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        outs, ready = [], None
+
+        def launch(b):
+            side.wait_stream(main)                    # inputs prepared on the current stream
+            with torch.cuda.stream(side):
+                fused = self.retrieve(*b[:5])
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for t in fused:
+                t.record_stream(main)                 # consumed on the current stream later
+            return fused, ev
+        nxt = launch(batches[0])
+        for i, b in enumerate(batches):
+            fused, ev = nxt
+            if i + 1 < len(batches):
+                nxt = launch(batches[i + 1])
+            main.wait_event(ev)
+            outs.append(self.finish(fused, *b[5:7]))
+        return outs

@@ -149,3 +149,45 @@ def test_simple_reranker_scores_from_resident_rows():
     score, row, cnt = vi.search_rows(e.encode(q), 20)
     by_rows = vi._index.rescore(vi.prepare_queries(e.encode(q)), row)[0]
     assert np.allclose(by_text, by_rows, atol=1e-5)
+
+
+def test_pipelined_batches_equal_one_by_one():
+    """search_many (retrieval of batch i+1 on a side stream under the rerank of batch i) returns
+    bit for bit what search returns batch by batch."""
+    import rag_hip
+    from indexing import bert
+    from indexing.batch import BatchSearcher, TokenStore
+    from indexing.bm25_indexer import build_arrays
+    from tests import synth
+    dev = torch.device('cuda:0')
+    n, dim, vocab, b = 20000, 64, 3000, 64
+    corpus = synth.dense_corpus(n, dim, seed=1)
+    term, doc, ln = synth.sparse_corpus(n, vocab, seed=2, mean_len=25)
+    arr = build_arrays(term, doc, ln, vocab, 1.5, 0.75)
+    dense = rag_hip.DenseIndex(corpus)
+    bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n)
+    bi, _, _ = bert.load_model('random:tiny', 'bi', dev)
+    ce, _, _ = bert.load_model('random:tiny', 'cross', dev)
+    rng = np.random.default_rng(3)
+    off = np.concatenate([[0], np.cumsum(ln + 2)]).astype(np.int64)
+    tok = rng.integers(1000, 4096, size=int(off[-1])).astype(np.int32)
+    s = BatchSearcher(dense, bm25, canon=torch.from_numpy(np.arange(n, dtype=np.uint32)).to(dev), bi_encoder=bi,
+                      cross_encoder=ce, chunk_tokens=TokenStore(torch.from_numpy(tok).to(dev), torch.from_numpy(off).to(dev)),
+                      top_k=5, rerank_top_n=20)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    batches = []
+    for i in range(4):
+        q_ids = np.zeros((b, 12), np.int64)
+        q_ids[:, 0], q_ids[:, 11] = 101, 102
+        q_ids[:, 1:11] = rng.integers(1000, 4096, size=(b, 10))
+        qterms, qoff = rag_hip.Bm25Index.flatten(synth.sparse_queries(term, doc, ln, vocab, b, seed=10 + i))
+        batches.append((t(q_ids), t(np.ones((b, 12), np.int64)), t(qterms), t(qoff), int(qoff[-1]),
+                        t(q_ids[:, 1:11].astype(np.int32).reshape(-1)), t((np.arange(b + 1) * 10).astype(np.int64))))
+    one_by_one = [s.search(*bt) for bt in batches]
+    torch.cuda.synchronize()
+    for _ in range(2):                                  # twice: the second pass reuses freed blocks of both streams
+        piped = s.search_many(batches)
+        torch.cuda.synchronize()
+        for a, c in zip(one_by_one, piped):
+            for key in ('rows', 'scores', 'rerank_score', 'count', 'fused_row', 'fused_score', 'fused_count'):
+                assert torch.equal(a[key], c[key]), key
