@@ -33,6 +33,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <initializer_list>
 #include <type_traits>
 #include <utility>
 
@@ -673,6 +674,13 @@ extern "C" int rag_enc_mlp_debug(unsigned long long* out8) {
 
 namespace {
 
+// every matrix and vector is read or written in 16-byte pieces
+bool aligned16(std::initializer_list<const void*> ptrs) {
+    for (const void* q : ptrs)
+        if (reinterpret_cast<uintptr_t>(q) % 16 != 0) return false;
+    return true;
+}
+
 // Measurement aid: while enabled, every launch is bracketed by a HIP event pair on its stream.
 // One state per process (one process drives one GPU here); not thread safe.
 struct MlpProfile {
@@ -722,6 +730,7 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma && d_beta && d_y, RAG_EINVAL, "rag_enc_mlp: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_mlp: y must not alias x (x is read again as the residual)");
+    RAG_REQUIRE(aligned16({d_x, d_w1, d_w2, d_b2, d_gamma, d_beta, d_y}), RAG_EINVAL, "rag_enc_mlp: pointers must be 16-byte aligned");
     MlpParams p = {};
     p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
     p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.y = (bf16*)d_y;
@@ -743,6 +752,8 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_ctx && d_x && d_wo && d_bo && d_gamma1 && d_beta1 && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma2 && d_beta2 && d_y,
                 RAG_EINVAL, "rag_enc_attn_out_mlp: null pointer");
+    RAG_REQUIRE(aligned16({d_ctx, d_x, d_wo, d_bo, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
+                "rag_enc_attn_out_mlp: pointers must be 16-byte aligned");
     MlpParams p = {};
     p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
     p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma2; p.beta = (const bf16*)d_beta2; p.y = (bf16*)d_y;
@@ -795,6 +806,8 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_w && d_bias && d_y, RAG_EINVAL, "rag_enc_linear384: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_linear384: y must not alias x");
+    RAG_REQUIRE(aligned16({d_x, d_w, d_residual, d_gamma, d_beta, d_y}), RAG_EINVAL,
+                "rag_enc_linear384: pointers must be 16-byte aligned");
     RAG_REQUIRE(d_residual == nullptr || (n == ML_HID && d_gamma && d_beta), RAG_EINVAL,
                 "rag_enc_linear384: the residual + LayerNorm tail needs n == %d, gamma and beta", ML_HID);
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear384: too many rows");

@@ -123,6 +123,17 @@ def test_mlp_rows_are_independent():
     assert torch.equal(y[perm], y2)
 
 
+def test_misaligned_pointers_are_rejected():
+    import rag_hip
+    x, w1, b1, w2, b2, gamma, beta = _layer(8, 64, 1)
+    flat = torch.zeros(8 * 384 + 8, dtype=torch.bfloat16, device=x.device)
+    x_off = flat[1:1 + 8 * 384].view(8, 384)                # 2 bytes past a 16-byte boundary
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_mlp_dev(x_off, w1, b1, w2, b2, gamma, beta)
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_linear384_dev(x_off, w1, b1)
+
+
 def test_mlp_argument_errors():
     import rag_hip
     x, w1, b1, w2, b2, gamma, beta = _layer(8, 48, 1)
