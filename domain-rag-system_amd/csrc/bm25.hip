@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int BM_NT = 256;
-constexpr int BM_TILE = 4096;      // documents per tile (32 KB of fp64 accumulators)
+constexpr int BM_TILE = 2048;      // documents per tile (16 KB of fp64 accumulators)
 
 struct Bm25Params {
     const int64_t* indptr;
