@@ -15,8 +15,12 @@
 // reference's `score += idf * impact` loop: bit-identical fp64 results.  The tile then emits its
 // candidates for the query's top-K: documents whose score reaches the query's shared threshold,
 // cut to the tile's K best; the K-th best of a tile raises the shared threshold (a lower bound
-// of the final K-th score), which prunes later tiles.
-// Kernel 3 (merge_topk_kernel): per query, the K best of all tiles' candidates, sorted.
+// of the final K-th score), which prunes later tiles.  Candidates go to one append-only list per
+// query (a tile reserves its places with one atomic add).
+// Kernel 3 (merge_topk_kernel): per query, the K best of the query's candidate list, sorted.
+// With 64 tiles or more the tile kernel runs twice: first on a sample of one tile in sixteen, whose
+// merged K-th score seeds the shared threshold, then on the rest, which then emit about 16 K
+// candidates per query in all instead of dozens per tile.
 #include "common.h"
 #include "merge.h"
 
@@ -43,11 +47,12 @@ struct Bm25Params {
     int n_tiles;
     int k;
     unsigned long long* tau;       // [n_queries] shared score-key threshold
-    uint64_t* cand_key;            // [n_queries][n_tiles][k]
+    uint64_t* cand_key;            // [n_queries][n_tiles * k]: one append-only candidate list per query
     uint32_t* cand_row;
-    int32_t* cand_count;           // [n_queries][n_tiles]
+    int32_t* cand_count;           // [n_queries] candidates appended so far
     double* dense_out;             // scores mode: [n_docs]
     int share_tau;                 // tuning aid: 0 = tiles do not share their thresholds
+    int tile_base;                 // first tile of this launch
 };
 
 __global__ void bm25_offsets_kernel(Bm25Params p) {
@@ -79,10 +84,12 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
     __shared__ unsigned long long tau_s;
     __shared__ unsigned long long kmin_s;
     __shared__ int count_s[2];
+    __shared__ int base_s;
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x / p.n_queries;
-    const int q = blockIdx.x - tile * p.n_queries;
+    const int tile_in_launch = blockIdx.x / p.n_queries;
+    const int q = blockIdx.x - tile_in_launch * p.n_queries;
+    const int tile = p.tile_base + tile_in_launch;
     const int64_t r0 = (int64_t)tile * BM_TILE;
     const int n_in = (int)min((int64_t)BM_TILE, p.n_docs - r0);
 
@@ -137,13 +144,18 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
     __syncthreads();
     const int n_pass = count_s[0];
 
-    const size_t slot = ((size_t)q * p.n_tiles + tile) * p.k;
+    // Reserve this tile's place in the query's candidate list: every document that passes, or the k best.
+    const int n_emit = min(n_pass, p.k);
+    if (n_emit == 0) return;
+    if (tid == 0) base_s = atomicAdd(&p.cand_count[q], n_emit);
+    __syncthreads();
+    const size_t slot = (size_t)q * p.n_tiles * p.k + base_s;
     if (n_pass <= p.k) {
         for (int i = tid; i < n_in; i += BM_NT) {
             unsigned long long key = f64_to_key(acc[i]);
             if (key >= tau) {
                 int at = atomicAdd(&count_s[1], 1);
-                if (at < p.k) {
+                if (at < n_emit) {
                     p.cand_key[slot + at] = key;
                     p.cand_row[slot + at] = (uint32_t)(r0 + i);
                 }
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
             uint32_t row = (uint32_t)(r0 + i);
             if (sel_pass(thr, key, row)) {
                 int at = atomicAdd(&count_s[1], 1);
-                if (at < p.k) {
+                if (at < n_emit) {
                     p.cand_key[slot + at] = key;
                     p.cand_row[slot + at] = row;
                 }
@@ -171,12 +183,27 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
         if (kmin != ~0ull) atomicMin(&kmin_s, kmin);
     }
     __syncthreads();
-    if (tid == 0) {
-        if (count_s[1] > p.k) rag_flag(p.fault, RAG_FAULT_BM25_LIST);
-        p.cand_count[(size_t)q * p.n_tiles + tile] = min(count_s[1], p.k);
-        // only an exact selection proves that k documents reach kmin
-        if (p.share_tau && n_pass > p.k && count_s[1] == p.k) atomicMax(&p.tau[q], kmin_s);
+    const int n_written = count_s[1];
+    if (n_written != n_emit) {
+        // internal error: the reserved places must still hold defined entries (the lowest key, rows of
+        // this tile that were not emitted cannot be named here, so the merge may flag the list too)
+        if (tid == 0) rag_flag(p.fault, RAG_FAULT_BM25_LIST);
+        for (int i = max(n_written, 0) + tid; i < n_emit; i += BM_NT) {
+            p.cand_key[slot + i] = 0ull;
+            p.cand_row[slot + i] = (uint32_t)r0;
+        }
     }
+    // only an exact selection proves that k documents reach kmin
+    if (tid == 0 && p.share_tau && n_pass > p.k && n_written == p.k) atomicMax(&p.tau[q], kmin_s);
+}
+
+// The K-th best score of a merged sample of tiles is a lower bound of the final K-th score: raise the
+// query's threshold to it (the tiles raise it with atomicMax too, hence the same here).
+__global__ void bm25_tau_from_sample_kernel(const double* __restrict__ score, const int32_t* __restrict__ count,
+                                            int n_queries, int k, unsigned long long* __restrict__ tau) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    if (count[q] >= k) atomicMax(&tau[q], (unsigned long long)f64_to_key(score[(size_t)q * k + k - 1]));
 }
 
 }  // namespace
@@ -319,18 +346,36 @@ extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const 
     if ((rc = h->tau.ensure((size_t)n_queries * sizeof(unsigned long long)))) return rc;
     if ((rc = h->cand_key.ensure(slots * k * sizeof(uint64_t)))) return rc;
     if ((rc = h->cand_row.ensure(slots * k * sizeof(uint32_t)))) return rc;
-    if ((rc = h->cand_count.ensure(slots * sizeof(int32_t)))) return rc;
+    if ((rc = h->cand_count.ensure((size_t)n_queries * sizeof(int32_t)))) return rc;
     p.tau = (unsigned long long*)h->tau.p;
     p.cand_key = (uint64_t*)h->cand_key.p;
     p.cand_row = (uint32_t*)h->cand_row.p;
     p.cand_count = (int32_t*)h->cand_count.p;
     RAG_HIP_TRY(hipMemsetAsync(p.tau, 0, (size_t)n_queries * sizeof(unsigned long long), stream));
+    RAG_HIP_TRY(hipMemsetAsync(p.cand_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
     const int64_t n_blocks = (int64_t)p.n_tiles * n_queries;
     RAG_REQUIRE(n_blocks < (1ll << 31), RAG_ELIMIT, "rag_bm25_search: %lld workgroups exceed the grid limit",
                 (long long)n_blocks);
-    bm25_tile_kernel<false><<<(unsigned)n_blocks, BM_NT, 0, stream>>>(p);
+    // The threshold the tiles share while they run is the best single-tile K-th score, far below the final
+    // K-th score.  With many tiles, a sample of them is scored and merged first: its K-th score is a much
+    // tighter bound, and the remaining tiles then emit a handful of candidates each instead of dozens.
+    int sample = 0;
+    // One tile in sixteen (at most 32): the sample's K-th score then leaves about 16 K candidates in all.
+    if (p.share_tau && p.n_tiles >= 64 && !getenv("RAG_BM25_NO_SAMPLE")) sample = std::min(32, p.n_tiles / 16);
+    if (sample) {
+        p.tile_base = 0;
+        bm25_tile_kernel<false><<<(unsigned)((int64_t)sample * n_queries), BM_NT, 0, stream>>>(p);
+        RAG_HIP_TRY(hipGetLastError());
+        rc = launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, (int64_t)p.n_tiles * k, k, h->row_base,
+                                 d_out_score, d_out_row, d_out_count, p.fault, stream);
+        if (rc) return rc;
+        bm25_tau_from_sample_kernel<<<(n_queries + 255) / 256, 256, 0, stream>>>(d_out_score, d_out_count, n_queries, k, p.tau);
+        RAG_HIP_TRY(hipGetLastError());
+    }
+    p.tile_base = sample;
+    bm25_tile_kernel<false><<<(unsigned)((int64_t)(p.n_tiles - sample) * n_queries), BM_NT, 0, stream>>>(p);
     RAG_HIP_TRY(hipGetLastError());
-    return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, p.n_tiles, k, k, h->row_base,
+    return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, (int64_t)p.n_tiles * k, k, h->row_base,
                                d_out_score, d_out_row, d_out_count, p.fault, stream);
 }
 

@@ -560,7 +560,7 @@ extern "C" int rag_merge_topk_f32_dev(const float* d_score, const int64_t* d_row
     RAG_REQUIRE(d_score && d_row && d_out_score && d_out_row && d_out_count, RAG_EINVAL, "rag_merge_topk: null pointer");
     ragmerge::ListF32Src src{d_score, d_row, d_count, n_lists, k_in, smaller_is_better ? 1 : 0};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       (hipStream_t)stream, src, n_lists * k_in, k_out, (int64_t)0, smaller_is_better ? 1 : 0,
+                       (hipStream_t)stream, src, k_out, (int64_t)0, smaller_is_better ? 1 : 0,
                        d_out_score, d_out_row, d_out_count, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
@@ -575,7 +575,7 @@ extern "C" int rag_merge_topk_f64_dev(const double* d_score, const int64_t* d_ro
     RAG_REQUIRE(d_score && d_row && d_out_score && d_out_row && d_out_count, RAG_EINVAL, "rag_merge_topk: null pointer");
     ragmerge::ListF64Src src{d_score, d_row, d_count, n_lists, k_in};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF64Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       (hipStream_t)stream, src, n_lists * k_in, k_out, (int64_t)0, 0, d_out_score, d_out_row,
+                       (hipStream_t)stream, src, k_out, (int64_t)0, 0, d_out_score, d_out_row,
                        d_out_count, rag_fault_word());
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;

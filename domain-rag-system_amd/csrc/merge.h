@@ -17,6 +17,8 @@ struct Cand32Src {                 // dense scan output: (key, local row) pairs 
     const int32_t* count;
     int n_lists, k_in;
     typedef uint32_t key_t;
+    static constexpr bool dense = false;
+    __device__ int size(int) const { return n_lists * k_in; }
     __device__ bool get(int q, int i, uint32_t& key, uint32_t& row) const {
         int list = i / k_in, j = i - list * k_in;
         if (j >= count[(size_t)q * n_lists + list]) { key = 0; row = 0; return false; }
@@ -25,16 +27,18 @@ struct Cand32Src {                 // dense scan output: (key, local row) pairs 
         return true;
     }
 };
-struct Cand64Src {                 // BM25 scan output
-    const uint64_t* key;
+struct Cand64Src {                 // BM25 scan output: one append-only list per query
+    const uint64_t* key;           // [n_queries][capacity]
     const uint32_t* row;
-    const int32_t* count;
-    int n_lists, k_in;
+    const int32_t* count;          // [n_queries] entries appended so far
+    int64_t capacity;
     typedef uint64_t key_t;
+    // Every entry below size(q) is valid, and the scan's threshold keeps the list short: the merge copies it
+    // into LDS and selects there.
+    static constexpr bool dense = true;
+    __device__ int size(int q) const { return count[q]; }
     __device__ bool get(int q, int i, uint64_t& k, uint32_t& r) const {
-        int list = i / k_in, j = i - list * k_in;
-        if (j >= count[(size_t)q * n_lists + list]) { k = 0; r = 0; return false; }
-        size_t at = ((size_t)q * n_lists + list) * k_in + j;
+        size_t at = (size_t)q * capacity + i;
         k = key[at]; r = row[at];
         return true;
     }
@@ -45,6 +49,8 @@ struct ListF32Src {                // public merge: fp32 scores + int64 global r
     const int32_t* count;          // may be null: then row < 0 marks an unused slot
     int n_lists, k_in, invert;
     typedef uint32_t key_t;
+    static constexpr bool dense = false;
+    __device__ int size(int) const { return n_lists * k_in; }
     __device__ bool get(int q, int i, uint32_t& key, uint32_t& row) const {
         int list = i / k_in, j = i - list * k_in;
         size_t at = ((size_t)q * n_lists + list) * k_in + j;
@@ -62,6 +68,8 @@ struct ListF64Src {
     const int32_t* count;
     int n_lists, k_in;
     typedef uint64_t key_t;
+    static constexpr bool dense = false;
+    __device__ int size(int) const { return n_lists * k_in; }
     __device__ bool get(int q, int i, uint64_t& key, uint32_t& row) const {
         int list = i / k_in, j = i - list * k_in;
         size_t at = ((size_t)q * n_lists + list) * k_in + j;
@@ -85,59 +93,35 @@ template <> struct ScoreOf<uint64_t> {
     __device__ static double empty() { return 0.0; }
 };
 
-template <typename Src>
-__global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_items, int k_out, int64_t row_base,
-                                                              int invert,
-                                                              typename ScoreOf<typename Src::key_t>::type* out_score,
-                                                              int64_t* out_row, int32_t* out_count,
-                                                              uint32_t* fault) {
-    typedef typename Src::key_t KeyT;
-    typedef typename ScoreOf<KeyT>::type ScoreT;
-    __shared__ __attribute__((aligned(16))) uint32_t sel_lds[RAG_SEL_LDS_WORDS];
-    __shared__ KeyT sel_key[RAG_MAX_K];
-    __shared__ uint32_t sel_row[RAG_MAX_K];
-    __shared__ int counter[2];
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
+// Entries a compactable source may hold for the merge to stage them in LDS (12 bytes each for 64-bit keys).
+constexpr int MERGE_COMPACT = 4096;
 
-    if (tid < 2) counter[tid] = 0;
-    __syncthreads();
-    int local_valid = 0;
-    for (int i = tid; i < n_items; i += MERGE_NT) {
+// Select the K best of n items, order them, write (score, global row).  Every thread of the block calls.
+template <typename KeyT, typename Get>
+__device__ __forceinline__ void select_and_emit(Get get, int n, int K, int64_t row_base, int invert,
+                                                typename ScoreOf<KeyT>::type* os, int64_t* orow, int32_t* out_count_q,
+                                                uint32_t* fault, uint32_t* sel_lds, KeyT* sel_key, uint32_t* sel_row,
+                                                int* gathered, int tid) {
+    auto load = [&](int i, KeyT& key, uint32_t& row) { get(i, key, row); };
+    SelThr<KeyT> thr = radix_select<KeyT, MERGE_NT>(load, n, K, sel_lds, tid);
+
+    for (int i = tid; i < n; i += MERGE_NT) {
         KeyT key; uint32_t row;
-        local_valid += src.get(q, i, key, row) ? 1 : 0;
-    }
-    if (local_valid) atomicAdd(&counter[0], local_valid);
-    __syncthreads();
-    const int n_valid = counter[0];
-    const int K = min(k_out, n_valid);
-
-    ScoreT* os = out_score + (size_t)q * k_out;
-    int64_t* orow = out_row + (size_t)q * k_out;
-    for (int i = K + tid; i < k_out; i += MERGE_NT) { os[i] = ScoreOf<KeyT>::empty(); orow[i] = -1; }
-    if (tid == 0) out_count[q] = K;
-    if (K == 0) return;
-
-    auto get = [&](int i, KeyT& key, uint32_t& row) { src.get(q, i, key, row); };
-    SelThr<KeyT> thr = radix_select<KeyT, MERGE_NT>(get, n_items, K, sel_lds, tid);
-
-    for (int i = tid; i < n_items; i += MERGE_NT) {
-        KeyT key; uint32_t row;
-        bool ok = src.get(q, i, key, row);
+        bool ok = get(i, key, row);
         if (ok && sel_pass(thr, key, row)) {
-            int at = atomicAdd(&counter[1], 1);
+            int at = atomicAdd(gathered, 1);
             if (at < RAG_MAX_K) { sel_key[at] = key; sel_row[at] = row; }
         }
     }
     __syncthreads();
     // the selection yields exactly K entries; anything else is an internal error: report it
     // and emit only entries that were really gathered
-    const int got = min(counter[1], RAG_MAX_K);
+    const int got = min(*gathered, RAG_MAX_K);
     const int kept = min(got, K);
     if (got != K) {
         if (tid == 0) {
             rag_flag(fault, RAG_FAULT_MERGE_SHORT);
-            out_count[q] = kept;
+            *out_count_q = kept;
         }
         for (int i = kept + tid; i < K; i += MERGE_NT) { os[i] = ScoreOf<KeyT>::empty(); orow[i] = -1; }
     }
@@ -156,6 +140,65 @@ __global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int n_ite
     }
 }
 
+template <typename Src>
+__global__ __launch_bounds__(MERGE_NT) void merge_topk_kernel(Src src, int k_out, int64_t row_base, int invert,
+                                                              typename ScoreOf<typename Src::key_t>::type* out_score,
+                                                              int64_t* out_row, int32_t* out_count,
+                                                              uint32_t* fault) {
+    typedef typename Src::key_t KeyT;
+    typedef typename ScoreOf<KeyT>::type ScoreT;
+    constexpr int STAGE = Src::dense ? MERGE_COMPACT : 1;
+    __shared__ __attribute__((aligned(16))) uint32_t sel_lds[RAG_SEL_LDS_WORDS];
+    __shared__ KeyT sel_key[RAG_MAX_K];
+    __shared__ uint32_t sel_row[RAG_MAX_K];
+    __shared__ KeyT stage_key[STAGE];
+    __shared__ uint32_t stage_row[STAGE];
+    __shared__ int counter[2];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n_items = src.size(q);
+
+    if (tid < 2) counter[tid] = 0;
+    __syncthreads();
+    int n_valid = n_items;
+    if constexpr (!Src::dense) {
+        int local_valid = 0;
+        for (int i = tid; i < n_items; i += MERGE_NT) {
+            KeyT key; uint32_t row;
+            local_valid += src.get(q, i, key, row) ? 1 : 0;
+        }
+        if (local_valid) atomicAdd(&counter[0], local_valid);
+        __syncthreads();
+        n_valid = counter[0];
+    }
+    const int K = min(k_out, n_valid);
+
+    ScoreT* os = out_score + (size_t)q * k_out;
+    int64_t* orow = out_row + (size_t)q * k_out;
+    for (int i = K + tid; i < k_out; i += MERGE_NT) { os[i] = ScoreOf<KeyT>::empty(); orow[i] = -1; }
+    if (tid == 0) out_count[q] = K;
+    if (K == 0) return;
+
+    if constexpr (Src::dense) {
+        if (n_items <= MERGE_COMPACT) {
+            for (int i = tid; i < n_items; i += MERGE_NT) {
+                KeyT key; uint32_t row;
+                src.get(q, i, key, row);
+                stage_key[i] = key;
+                stage_row[i] = row;
+            }
+            __syncthreads();
+            auto get = [&](int i, KeyT& key, uint32_t& row) { key = stage_key[i]; row = stage_row[i]; return true; };
+            select_and_emit<KeyT>(get, n_items, K, row_base, invert, os, orow, out_count + q, fault, sel_lds, sel_key,
+                                  sel_row, &counter[1], tid);
+            return;
+        }
+    }
+    auto get = [&](int i, KeyT& key, uint32_t& row) { return src.get(q, i, key, row); };
+    select_and_emit<KeyT>(get, n_items, K, row_base, invert, os, orow, out_count + q, fault, sel_lds, sel_key, sel_row,
+                          &counter[1], tid);
+}
+
 }  // namespace
 }  // namespace ragmerge
 
@@ -164,17 +207,17 @@ static inline int launch_merge_cand32(const uint2* cand, const int32_t* count, i
                                       int32_t* out_count, uint32_t* fault, hipStream_t stream) {
     ragmerge::Cand32Src src{cand, count, n_lists, k_in};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::Cand32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count, fault);
+                       stream, src, k_out, row_base, 0, out_score, out_row, out_count, fault);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
 static inline int launch_merge_cand64(const uint64_t* key, const uint32_t* row, const int32_t* count, int n_queries,
-                                      int n_lists, int k_in, int k_out, int64_t row_base, double* out_score,
+                                      int64_t capacity, int k_out, int64_t row_base, double* out_score,
                                       int64_t* out_row, int32_t* out_count, uint32_t* fault, hipStream_t stream) {
-    ragmerge::Cand64Src src{key, row, count, n_lists, k_in};
+    ragmerge::Cand64Src src{key, row, count, capacity};
     hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::Cand64Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
-                       stream, src, n_lists * k_in, k_out, row_base, 0, out_score, out_row, out_count, fault);
+                       stream, src, k_out, row_base, 0, out_score, out_row, out_count, fault);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

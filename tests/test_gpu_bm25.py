@@ -60,7 +60,8 @@ def test_bm25_negative_idf_floor_is_exercised():
 
 
 @pytest.mark.parametrize('n_docs,vocab,b,k', [(3000, 500, 40, 10), (20000, 5000, 64, 20), (9000, 2000, 30, 200),
-                                              (4097, 300, 10, 1), (100, 50, 5, 100)])
+                                              (4097, 300, 10, 1), (100, 50, 5, 100),
+                                              (140000, 20000, 24, 50)])   # enough tiles for the sampled threshold
 def test_bm25_topk_matches_oracle(n_docs, vocab, b, k):
     import rag_hip
     from indexing.bm25_indexer import build_arrays

@@ -96,6 +96,15 @@ def test_bm25_1m_properties():
         order = np.argsort(dense_scores, kind='stable')[::-1][:100]
         assert np.array_equal(row[i], order), i
         assert np.array_equal(score[i], dense_scores[order])
+    # the threshold seeded from a sample of tiles changes the work, never the result
+    import os
+    for knob in ('RAG_BM25_NO_SAMPLE', 'RAG_BM25_NO_TAU'):
+        os.environ[knob] = '1'
+        try:
+            score2, row2, cnt2 = idx.search(big[:256], 100)
+        finally:
+            del os.environ[knob]
+        assert np.array_equal(row2, row[:256]) and np.array_equal(score2, score[:256]) and np.array_equal(cnt2, cnt[:256])
     ref = BM25OkapiArrays.from_token_ids(term, doc, ln, VOCAB)
     assert np.array_equal(ref.idf, arr.idf)
     for i in (0, 6, 40):
