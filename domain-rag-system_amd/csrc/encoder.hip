@@ -260,8 +260,12 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
 }
 
 // fp32 attention for the bi-encoder (its embeddings must hold 1e-4 on cosine scores, so its
-// forward stays in fp32): one wave per (sequence, head), one query row per lane, keys and values
-// of 64-key chunks broadcast from LDS, two-pass softmax per chunk with a running maximum.
+// forward stays in fp32): one wave per (sequence, head).  Queries are short (a dozen tokens), so a lane
+// per query row would leave most of the wave idle: the wave takes 16 query rows at a time and the four
+// lanes of a row own a quarter of the head's dimensions each (partial dot products, summed across the
+// four with two shuffles; a quarter of the output row each).  Keys and values go through LDS in blocks
+// of 16 (8 KB for 64 dimensions, so a dozen waves fit a compute unit), loaded with every request of a
+// block in flight at once; two-pass softmax per block with a running maximum.
 // The arithmetic is tiny next to the GEMMs (a few GFLOP per batch); plain FMAs, no MFMA.
 template <int D>
 __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv,
@@ -269,9 +273,14 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
                                                            const int32_t* __restrict__ cu, int64_t total_tokens,
                                                            int n_seq, int S_max, int NH, float scale,
                                                            float* __restrict__ out, uint32_t* fault) {
-    __shared__ __attribute__((aligned(16))) float Ks[64][D];
-    __shared__ __attribute__((aligned(16))) float Vs[64][D];
+    constexpr int KB = 16;                       // keys per block
+    constexpr int DG = D / 4;                    // dimensions per lane of a query row
+    constexpr int NIT = KB * (D / 4) / 64;       // 16-byte pieces of a K (or V) block per lane
+    static_assert(DG % 4 == 0 && NIT >= 1, "head dimension must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float Ks[KB][D];
+    __shared__ __attribute__((aligned(16))) float Vs[KB][D];
     const int lane = threadIdx.x;
+    const int qi = lane & 15, g = lane >> 4;
     const int jb = blockIdx.x >> 3;
     const int head = jb % NH;
     const int seq = (jb / NH) * 8 + (blockIdx.x & 7);
@@ -297,74 +306,89 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
     const float* base = qkv + (size_t)first * tok + head * D;
     float* obase = out + (size_t)first * H + head * D;
 
-    for (int q0 = 0; q0 < S; q0 += 64) {
-        const int q = q0 + lane;
+    for (int q0 = 0; q0 < S; q0 += 16) {
+        const int q = q0 + qi;
         const bool live = q < S && len > 0;
-        float qv[D], o[D];
+        float qv[DG], o[DG];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { qv[d] = 0.f; o[d] = 0.f; }
+        for (int d = 0; d < DG; ++d) { qv[d] = 0.f; o[d] = 0.f; }
         if (live) {
 #pragma unroll
-            for (int d = 0; d < D; d += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * tok + d);
+            for (int d = 0; d < DG; d += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * tok + g * DG + d);
                 qv[d] = v.x * scale; qv[d + 1] = v.y * scale; qv[d + 2] = v.z * scale; qv[d + 3] = v.w * scale;
             }
         }
         float m_run = NEG_BIG, l_run = 0.f;
-        for (int k0 = 0; k0 < len; k0 += 64) {
-            const int nk = min(64, len - k0);
-            __syncthreads();                              // the previous chunk has been consumed
-            const int nk16 = (nk + 15) & ~15;             // rows up to the next 16 are read: zero them
-            for (int i = lane; i < nk16 * (D / 4); i += 64) {
+        for (int kb = 0; kb < len; kb += KB) {
+            const int nk = min(KB, len - kb);
+            float4 kreg[NIT], vreg[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = lane + 64 * it;
                 const int key = i / (D / 4), c = i - key * (D / 4);
-                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-                if (key < nk) {
-                    const float* p = base + (size_t)(k0 + key) * tok + c * 4;
-                    kv = *reinterpret_cast<const float4*>(p + H);
-                    vv = *reinterpret_cast<const float4*>(p + 2 * H);
+                kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vreg[it] = kreg[it];
+                if (key < nk) {                           // rows beyond the sequence read as zero
+                    const float* p = base + (size_t)(kb + key) * tok + c * 4;
+                    kreg[it] = *reinterpret_cast<const float4*>(p + H);
+                    vreg[it] = *reinterpret_cast<const float4*>(p + 2 * H);
                 }
-                *reinterpret_cast<float4*>(&Ks[key][c * 4]) = kv;
-                *reinterpret_cast<float4*>(&Vs[key][c * 4]) = vv;
+            }
+            __syncthreads();                              // the previous block has been consumed
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = lane + 64 * it;
+                const int key = i / (D / 4), c = i - key * (D / 4);
+                *reinterpret_cast<float4*>(&Ks[key][c * 4]) = kreg[it];
+                *reinterpret_cast<float4*>(&Vs[key][c * 4]) = vreg[it];
             }
             __syncthreads();
-            for (int kb = 0; kb < nk; kb += 16) {
-                float sc[16];
-                float mx = NEG_BIG;
+            float sc[KB];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    float a = 0.f;
+            for (int k = 0; k < KB; ++k) {
+                float a = 0.f;
 #pragma unroll
-                    for (int d = 0; d < D; d += 4) {
-                        const float4 kv = *reinterpret_cast<const float4*>(&Ks[kb + k][d]);
-                        a += qv[d] * kv.x + qv[d + 1] * kv.y + qv[d + 2] * kv.z + qv[d + 3] * kv.w;
-                    }
-                    sc[k] = kb + k < nk ? a : NEG_BIG;
-                    mx = fmaxf(mx, sc[k]);
+                for (int d = 0; d < DG; d += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(&Ks[k][g * DG + d]);
+                    a = fmaf(qv[d], kv.x, a); a = fmaf(qv[d + 1], kv.y, a);
+                    a = fmaf(qv[d + 2], kv.z, a); a = fmaf(qv[d + 3], kv.w, a);
                 }
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = expf(m_run - m_new);
-#pragma unroll
-                for (int d = 0; d < D; ++d) o[d] *= alpha;
-                float sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float pk = kb + k < nk ? expf(sc[k] - m_new) : 0.f;
-                    sum += pk;
-#pragma unroll
-                    for (int d = 0; d < D; d += 4) {
-                        const float4 vv = *reinterpret_cast<const float4*>(&Vs[kb + k][d]);
-                        o[d] += pk * vv.x; o[d + 1] += pk * vv.y; o[d + 2] += pk * vv.z; o[d + 3] += pk * vv.w;
-                    }
-                }
-                l_run = l_run * alpha + sum;
-                m_run = m_new;
+                sc[k] = a;
             }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                float a = sc[k];
+                a += __shfl_xor(a, 16, 64);
+                a += __shfl_xor(a, 32, 64);               // every lane of the row now holds the same sum
+                sc[k] = k < nk ? a : NEG_BIG;
+                mx = fmaxf(mx, sc[k]);
+            }
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);
+#pragma unroll
+            for (int d = 0; d < DG; ++d) o[d] *= alpha;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const float pk = k < nk ? expf(sc[k] - m_new) : 0.f;
+                sum += pk;
+#pragma unroll
+                for (int d = 0; d < DG; d += 4) {
+                    const float4 vv = *reinterpret_cast<const float4*>(&Vs[k][g * DG + d]);
+                    o[d] = fmaf(pk, vv.x, o[d]); o[d + 1] = fmaf(pk, vv.y, o[d + 1]);
+                    o[d + 2] = fmaf(pk, vv.z, o[d + 2]); o[d + 3] = fmaf(pk, vv.w, o[d + 3]);
+                }
+            }
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
         }
         if (q < S) {
             const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
 #pragma unroll
-            for (int d = 0; d < D; d += 4)
-                *reinterpret_cast<float4*>(obase + (size_t)q * H + d) =
+            for (int d = 0; d < DG; d += 4)
+                *reinterpret_cast<float4*>(obase + (size_t)q * H + g * DG + d) =
                     make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
         }
     }
