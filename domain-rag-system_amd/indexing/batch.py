@@ -58,6 +58,7 @@ class BatchSearcher:
         self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
         # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
+        self.ce_sort_by_length = True
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
             and next(cross_encoder.parameters()).dtype == torch.bfloat16)
@@ -190,7 +191,19 @@ class BatchSearcher:
             logits_mine[idx] = out.float()
 
     def _ce_packed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
-        """Pairs in their own order as unpadded token streams: no padding inside a pair is
+        """Longest pairs first: a mini-batch then holds pairs of similar length, and the attention kernel,
+        whose LDS image is sized by the mini-batch's longest pair, fits more workgroups per compute unit on
+        all but the first one.  A pair's logit does not depend on its place in the stream."""
+        if not self.ce_sort_by_length or my_r.shape[0] < 2:
+            return self._ce_packed_stream(q_tok, q_off, my_q, my_r, plen, logits_mine)
+        order = torch.argsort(plen, descending=True, stable=True)
+        sorted_logits = torch.zeros_like(logits_mine)
+        self._ce_packed_stream(q_tok, q_off, my_q[order].contiguous(), my_r[order].contiguous(),
+                               plen[order].contiguous(), sorted_logits)
+        logits_mine[order] = sorted_logits
+
+    def _ce_packed_stream(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+        """Pairs in the given order as unpadded token streams: no padding inside a pair is
         computed at all (bfloat16 model, librag_hip encoder kernels).  The stream is cut at
         pair boundaries into mini-batches of at most `ce_tokens_per_batch` tokens, each rounded
         up to a multiple of `ce_token_bucket` with unused tail tokens, so the GEMMs see only a
