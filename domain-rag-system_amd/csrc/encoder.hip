@@ -501,6 +501,77 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict_
     }
 }
 
+// LayerNorm((y + bias) + residual) in fp32, written as fp32 and, for the split-precision GEMM that reads it
+// next, as the bf16 row [hi | hi | lo] as well (out_split may be null).  One wave per row.
+__global__ __launch_bounds__(256) void bias_add_layernorm_split_kernel(const float* __restrict__ y,
+                                                                       const float* __restrict__ bias,
+                                                                       const float* __restrict__ res,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float eps,
+                                                                       int64_t rows, int H, float* __restrict__ out,
+                                                                       bf16* __restrict__ out_split) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n_chunks = H / 8;
+    float v[LN_MAX_CHUNKS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float bb[8], rr[8];
+            Vec8<float>::load(y + row * H + ch * 8, v[c]);
+            Vec8<float>::load(bias + ch * 8, bb);
+            Vec8<float>::load(res + row * H + ch * 8, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = (v[c][j] + bb[j]) + rr[j];
+                sum += v[c][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; sq += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < n_chunks) {
+            float g[8], b[8], o[8];
+            Vec8<float>::load(gamma + ch * 8, g);
+            Vec8<float>::load(beta + ch * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+            Vec8<float>::store(out + row * H + ch * 8, o);
+            if (out_split != nullptr) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hi[j] = (bf16)o[j];
+                    lo[j] = (bf16)(o[j] - (float)hi[j]);
+                }
+                bf16* p = out_split + row * 3 * H + ch * 8;
+                *reinterpret_cast<bf16x8*>(p) = hi;
+                *reinterpret_cast<bf16x8*>(p + H) = hi;
+                *reinterpret_cast<bf16x8*>(p + 2 * H) = lo;
+            }
+        }
+    }
+}
+
 // LayerNorm(word[id] + position[pos] + type[tt]) per token, one wave per token.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __restrict__ ids,
@@ -733,6 +804,52 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 }  // namespace
 
+namespace {
+// The same split applied to act(y + bias): what stands between two split-precision GEMMs of the feed-forward
+// block (bias add, GELU and split were three passes over the widest activation of the layer).
+template <bool GELU>
+__global__ __launch_bounds__(256) void bias_act_split_bf16x3_kernel(const float* __restrict__ y,
+                                                                    const float* __restrict__ bias, int64_t rows, int K,
+                                                                    bf16* __restrict__ out) {
+    const int64_t n8 = rows * (K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / (K / 8);
+        const int c = (int)(i - row * (K / 8));
+        float f[8], b[8];
+        Vec8<float>::load(y + row * K + c * 8, f);
+        Vec8<float>::load(bias + c * 8, b);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f[j] += b[j];
+            if (GELU) f[j] = 0.5f * f[j] * (1.0f + erff(f[j] * 0.70710678118654752f));
+            hi[j] = (bf16)f[j];
+            lo[j] = (bf16)(f[j] - (float)hi[j]);
+        }
+        bf16* o = out + row * 3 * K + c * 8;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + K) = hi;
+        *reinterpret_cast<bf16x8*>(o + 2 * K) = lo;
+    }
+}
+}  // namespace
+
+extern "C" int rag_enc_bias_act_split_bf16x3_dev(const float* d_y, const float* d_bias, int32_t gelu, int64_t rows,
+                                                 int32_t k, void* d_out, void* stream_) {
+    RAG_REQUIRE(rows >= 0 && k >= 8 && k % 8 == 0, RAG_EINVAL,
+                "rag_enc_bias_act_split_bf16x3: k must be a positive multiple of 8");
+    if (rows == 0) return RAG_OK;
+    RAG_REQUIRE(d_y && d_bias && d_out, RAG_EINVAL, "rag_enc_bias_act_split_bf16x3: null pointer");
+    const int64_t n8 = rows * (k / 8);
+    const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
+    if (gelu)
+        bias_act_split_bf16x3_kernel<true><<<grid, 256, 0, (hipStream_t)stream_>>>(d_y, d_bias, rows, k, (bf16*)d_out);
+    else
+        bias_act_split_bf16x3_kernel<false><<<grid, 256, 0, (hipStream_t)stream_>>>(d_y, d_bias, rows, k, (bf16*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream_) {
     RAG_REQUIRE(rows >= 0 && k >= 8 && k % 8 == 0, RAG_EINVAL, "rag_enc_split_bf16x3: k must be a positive multiple of 8");
     if (rows == 0) return RAG_OK;
@@ -740,6 +857,21 @@ extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t 
     const int64_t n8 = rows * (k / 8);
     const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
     split_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (bf16*)d_out);
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, const float* d_residual,
+                                                   const float* d_gamma, const float* d_beta, float eps, int64_t rows,
+                                                   int32_t hidden, float* d_out, void* d_out_split, void* stream_) {
+    RAG_REQUIRE(rows >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
+                "rag_enc_bias_add_layernorm_split: hidden must be a multiple of 8 up to %d", 8 * 64 * LN_MAX_CHUNKS);
+    if (rows == 0) return RAG_OK;
+    RAG_REQUIRE(d_y && d_bias && d_residual && d_gamma && d_beta && d_out, RAG_EINVAL,
+                "rag_enc_bias_add_layernorm_split: null pointer");
+    RAG_REQUIRE((rows + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_bias_add_layernorm_split: too many rows");
+    bias_add_layernorm_split_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(
+        d_y, d_bias, d_residual, d_gamma, d_beta, eps, rows, hidden, d_out, (bf16*)d_out_split);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

@@ -103,6 +103,7 @@ class BertEncoder(nn.Module):
         self.native = False          # set by load_model(native=True): use the librag_hip encoder kernels
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
+        self.fused_split_tails = True   # with split_gemm: one kernel for the work between two GEMMs
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
@@ -166,6 +167,8 @@ class BertEncoder(nn.Module):
         x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
+        if self.split_gemm and self.fused_split_tails and x.dtype == torch.float32:
+            return self._forward_packed_split(x, cu_seqlens, max_seq_len)
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
         for li, l in enumerate(self.layers):
@@ -233,17 +236,40 @@ class BertEncoder(nn.Module):
         return rag_hip.enc_add_layernorm_dev(lin(l.ffn_out, rag_hip.enc_gelu_(lin(l.ffn_in, x))), x, l.ffn_norm.weight,
                                              l.ffn_norm.bias, l.ffn_norm.eps)
 
+    def _split_weight(self, module):
+        import rag_hip
+        w3 = self._split_cache.get(id(module))
+        if w3 is None:
+            w3 = rag_hip.split_weight_bf16x3(module.weight.detach())
+            self._split_cache[id(module)] = w3
+        return w3
+
+    def _forward_packed_split(self, x, cu_seqlens, max_seq_len):
+        """The fp32 layers with every GEMM as a split-bf16 product (see _linear_split) and the work between
+        two GEMMs in one kernel each: bias + residual + LayerNorm + split of the result, bias + GELU + split.
+        Same arithmetic in the same order as the separate kernels, so the same embeddings bit for bit."""
+        import rag_hip
+        mm = lambda a3, module: torch.mm(a3, self._split_weight(module).t(), out_dtype=torch.float32)
+        xs = rag_hip.enc_split_bf16x3_dev(x)
+        last = len(self.layers) - 1
+        for li, l in enumerate(self.layers):
+            qkv = mm(xs, l.qkv).add_(l.qkv.bias)
+            ctx = rag_hip.enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, l.heads)
+            x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(rag_hip.enc_split_bf16x3_dev(ctx), l.attn_out),
+                                                             l.attn_out.bias, x, l.attn_norm.weight, l.attn_norm.bias,
+                                                             l.attn_norm.eps)
+            hs = rag_hip.enc_bias_act_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, True)
+            x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(hs, l.ffn_out), l.ffn_out.bias, x, l.ffn_norm.weight,
+                                                             l.ffn_norm.bias, l.ffn_norm.eps, want_split=li != last)
+        return x
+
     def _linear_split(self, module, x):
         """fp32 Linear on the bf16 matrix cores: three bf16 products accumulated in fp32 inside one
         GEMM (operands split into bf16 high and low parts and laid side by side along K).  The
         result differs from the fp32 GEMM by about 1e-5 relative, far inside the 1e-4 the
         embeddings have to hold on cosine scores, at a fraction of the fp32 matrix-core time."""
         import rag_hip
-        w3 = self._split_cache.get(id(module))
-        if w3 is None:
-            w3 = rag_hip.split_weight_bf16x3(module.weight.detach())
-            self._split_cache[id(module)] = w3
-        y = torch.mm(rag_hip.enc_split_bf16x3_dev(x), w3.t(), out_dtype=torch.float32)
+        y = torch.mm(rag_hip.enc_split_bf16x3_dev(x), self._split_weight(module).t(), out_dtype=torch.float32)
         return y.add_(module.bias)
 
 

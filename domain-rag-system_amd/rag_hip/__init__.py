@@ -79,6 +79,8 @@ SIGNATURES = {
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    'rag_enc_bias_act_split_bf16x3_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'rag_enc_bias_add_layernorm_split_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _vp, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
                                       _i32, _vp, _vp, _vp, _vp]),
@@ -749,6 +751,38 @@ def enc_split_bf16x3_dev(x):
     check(lib().rag_enc_split_bf16x3_dev(_ptr(x, torch.float32), rows, k, _ptr(out), _stream()),
           'rag_enc_split_bf16x3_dev')
     return out
+
+
+def enc_bias_act_split_dev(y, bias, gelu):
+    """fp32 y [rows, K], bias [K] -> bf16 [rows, 3K] = split of act(y + bias), act = exact GELU or identity
+    (rag_enc_bias_act_split_bf16x3_dev)."""
+    import torch
+    rows, k = y.shape
+    if tuple(bias.shape) != (k,):
+        raise ValueError("bias must have one entry per column")
+    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=y.device)
+    check(lib().rag_enc_bias_act_split_bf16x3_dev(_ptr(y, torch.float32), _ptr(bias, torch.float32), 1 if gelu else 0,
+                                                  rows, k, _ptr(out), _stream()), 'rag_enc_bias_act_split_bf16x3_dev')
+    return out
+
+
+def enc_bias_add_layernorm_split_dev(y, bias, residual, gamma, beta, eps, want_split=True):
+    """fp32 LayerNorm((y + bias) + residual) -> (out fp32 [rows, H], its bf16 split [rows, 3H] or None)
+    (rag_enc_bias_add_layernorm_split_dev)."""
+    import torch
+    rows, h = y.shape
+    if residual.shape != y.shape:
+        raise ValueError("residual must have the shape of y")
+    if tuple(bias.shape) != (h,) or tuple(gamma.shape) != (h,) or tuple(beta.shape) != (h,):
+        raise ValueError("bias, gamma and beta must have one entry per hidden unit")
+    out = torch.empty_like(y)
+    split = torch.empty((rows, 3 * h), dtype=torch.bfloat16, device=y.device) if want_split else None
+    check(lib().rag_enc_bias_add_layernorm_split_dev(_ptr(y, torch.float32), _ptr(bias, torch.float32),
+                                                     _ptr(residual, torch.float32), _ptr(gamma, torch.float32),
+                                                     _ptr(beta, torch.float32), float(eps), rows, h, _ptr(out),
+                                                     _ptr(split) if split is not None else None, _stream()),
+          'rag_enc_bias_add_layernorm_split_dev')
+    return out, split
 
 
 def split_weight_bf16x3(w):

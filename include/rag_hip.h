@@ -362,6 +362,19 @@ int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
  * [w_hi ; w_lo ; w_hi] along k it yields x_hi w_hi + x_hi w_lo + x_lo w_hi, i.e. the fp32
  * product to about 2^-16 relative per term (the dropped x_lo w_lo term).               */
 int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream);
+/* The same split of act(y + bias) (bias [k] fp32; gelu != 0: exact erf GELU, else identity): what
+ * stands between the two split-precision GEMMs of BERT's feed-forward block
+ * (transformers BertIntermediate, reached through SentenceTransformer.encode,
+ * reference src/indexing/embedder.py:65-71).                                              */
+int rag_enc_bias_act_split_bf16x3_dev(const float* d_y, const float* d_bias, int32_t gelu, int64_t rows,
+                                      int32_t k, void* d_out, void* stream);
+/* out[r] = LayerNorm((y[r] + bias) + residual[r]) * gamma + beta in fp32 (BertSelfOutput /
+ * BertOutput behind reference src/indexing/embedder.py:65-71), and, when d_out_split is not
+ * NULL, the bf16 row [hi | hi | lo] of out[r] (3 * hidden elements) for the split-precision
+ * GEMM that reads it next.  hidden a multiple of 8 up to 2048; out may alias y or residual. */
+int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, const float* d_residual,
+                                         const float* d_gamma, const float* d_beta, float eps, int64_t rows,
+                                         int32_t hidden, float* d_out, void* d_out_split, void* stream);
 /* BERT's input embedding: out[t] = LayerNorm(word[ids[t]] + position[pos[t]] +
  * type_emb[types[t]]) (types NULL = all 0), tables [vocab|max_pos|n_types][hidden];
  * ids outside a table are clamped and flagged (RAG_FAULT_TOKEN).                        */

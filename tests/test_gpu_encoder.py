@@ -251,6 +251,44 @@ def test_split_bf16_gemm_embedder_holds_the_cosine_tolerance():
     assert float((a - p).abs().max()) < 2e-5
 
 
+def test_split_tails_equal_the_separate_kernels_bit_for_bit():
+    """bias + GELU + split and bias + residual + LayerNorm + split against the kernels they stand for;
+    the forward built from them gives the same embeddings as the one built from the separate kernels."""
+    import rag_hip
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(12)
+    for rows, k in ((1000, 3072), (37, 768), (1, 8)):
+        y = torch.randn((rows, k), generator=g, device=dev) * 2
+        bias = torch.randn((k,), generator=g, device=dev)
+        want = rag_hip.enc_split_bf16x3_dev(rag_hip.enc_gelu_((y + bias).contiguous()))
+        assert torch.equal(rag_hip.enc_bias_act_split_dev(y, bias, True), want)
+        assert torch.equal(rag_hip.enc_bias_act_split_dev(y, bias, False), rag_hip.enc_split_bf16x3_dev(y + bias))
+    for rows, h in ((1000, 768), (5, 384), (3, 2048)):
+        y = torch.randn((rows, h), generator=g, device=dev)
+        res = torch.randn((rows, h), generator=g, device=dev)
+        bias, gamma, beta = (torch.randn((h,), generator=g, device=dev) for _ in range(3))
+        want = rag_hip.enc_add_layernorm_dev(y + bias, res, gamma, beta, 1e-12)
+        out, split = rag_hip.enc_bias_add_layernorm_split_dev(y, bias, res, gamma, beta, 1e-12)
+        assert torch.equal(out, want) and torch.equal(split, rag_hip.enc_split_bf16x3_dev(want))
+        out, split = rag_hip.enc_bias_add_layernorm_split_dev(y, bias, res, gamma, beta, 1e-12, want_split=False)
+        assert torch.equal(out, want) and split is None
+    with pytest.raises(ValueError):
+        rag_hip.enc_bias_act_split_dev(y, bias[:-1].contiguous(), True)
+    model, _, cfg = bert.load_model('random:bert-base', 'bi', dev, native=True, split_gemm=True)
+    b, s = 48, 21
+    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev)
+    lens = torch.randint(3, s + 1, (b,), generator=g, device=dev)
+    mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
+    packed = model.bert.pack(ids, mask)
+    with torch.no_grad():
+        assert model.bert.fused_split_tails
+        fused = model.forward_packed(*packed, normalize=True)
+        model.bert.fused_split_tails = False
+        separate = model.forward_packed(*packed, normalize=True)
+    assert torch.equal(fused, separate)
+
+
 def test_first_token_attention_equals_row_zero_of_the_full_kernel():
     import rag_hip
     dev = torch.device('cuda:0')
