@@ -19,19 +19,22 @@
 #include "merge.h"
 
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;          // k-slice per stage
 constexpr int LDK = BK + 4;     // padded LDS row (floats): conflict-free ds_read_b128
 constexpr int BN = 128;         // rows per tile
 
 struct DenseScanParams {
-    const float* rows;          // [n_rows][dim]
-    const float* queries;       // [n_queries][dim]
+    const float* rows;          // [n_rows][dim] fp32, or the split image of the same size (see split_rows_kernel)
+    const float* queries;       // [n_queries][dim], likewise
     const float* row_norm2;     // [n_rows] or null (Euclidean only)
     const uint8_t* row_mask;    // [n_rows] or null
     int64_t n_rows;
@@ -48,6 +51,7 @@ struct DenseScanParams {
     uint32_t* tau_shared;       // [n_queries] key of a lower bound of each query's final K-th score
     uint32_t* fault;            // RAG_FAULT_* bits of this device (may be null)
     int euclid;
+    int split;                  // rows and queries are split images
     int debug_row_mod;          // tuning aid: when > 0, row loads wrap at this many rows (results meaningless)
 };
 
@@ -96,7 +100,13 @@ __device__ inline uint32_t wave_compact(uint2* list, int n, int K, uint32_t* sel
     return kmin;
 }
 
-template <int WQ, int TQ, int WR, int TR, bool EUCLID>
+// SPLIT: rows and queries are split images: each 32-wide k-slice of a row (128 bytes either way) holds the
+// bf16 high parts of its 32 values, then the bf16 low parts (x = hi + lo up to 2^-17 relative).  The
+// score tile is then hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation: three
+// v_mfma_f32_32x32x16_bf16 per 16 values of k instead of eight v_mfma_f32_32x32x2_f32, at a fifth of the
+// matrix time, with the same loads, LDS image and epilogue.  What is dropped (lo.lo) is below 2^-16 of
+// |x||q| in the worst case and about 1e-7 for unit vectors.
+template <int WQ, int TQ, int WR, int TR, bool EUCLID, bool SPLIT>
 __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanParams p) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
     constexpr int NT = Cfg::NT, NW = Cfg::NW, BQ = Cfg::BQ;
@@ -206,6 +216,41 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
 
         const float* eb = Es + buf * BN * LDK;
         const float* qbuf = Qs + buf * BQ * LDK;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // lane (row, half) feeds k = 16s + 8*half + 0..7 of the slice: 16 bytes of the high parts,
+                // 16 bytes of the low parts 64 bytes further on
+                bf16x8 ah[TR], al[TR], bh[TQ], bl[TQ];
+#pragma unroll
+                for (int tr = 0; tr < TR; ++tr) {
+                    const float* src = eb + ((wr * TR + tr) * 32 + lrow) * LDK + 8 * s + khalf;
+                    ah[tr] = *reinterpret_cast<const bf16x8*>(src);
+                    al[tr] = *reinterpret_cast<const bf16x8*>(src + 16);
+                }
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq) {
+                    const float* src = qbuf + ((wq * TQ + tq) * 32 + lrow) * LDK + 8 * s + khalf;
+                    bh[tq] = *reinterpret_cast<const bf16x8*>(src);
+                    bl[tq] = *reinterpret_cast<const bf16x8*>(src + 16);
+                }
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+                    for (int tr = 0; tr < TR; ++tr)
+                        acc[tq][tr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tr], bh[tq], acc[tq][tr], 0, 0, 0);
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+                    for (int tr = 0; tr < TR; ++tr)
+                        acc[tq][tr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tr], bl[tq], acc[tq][tr], 0, 0, 0);
+#pragma unroll
+                for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+                    for (int tr = 0; tr < TR; ++tr)
+                        acc[tq][tr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tr], bh[tq], acc[tq][tr], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             float4 a[TR], b[TQ];
@@ -226,6 +271,7 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
                         acc[tq][tr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tq][tr], 0, 0, 0);
                     }
             }
+        }
         }
 
         const int tile = st / k_stages;
@@ -324,6 +370,29 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
     }
 }
 
+// fp32 [n][dim] -> split image [n][dim / 32][hi x 32 | lo x 32] bf16 (dim a multiple of 32): one thread per
+// 8 values.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
+                                                         bf16* __restrict__ out) {
+    const int64_t n8 = n_rows * (dim / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / (dim / 8);
+        const int c = (int)(i - row * (dim / 8));          // 8-value group inside the row
+        const float4 v0 = *reinterpret_cast<const float4*>(x + row * dim + c * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(x + row * dim + c * 8 + 4);
+        const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (bf16)f[j];
+            lo[j] = (bf16)(f[j] - (float)hi[j]);
+        }
+        bf16* o = out + row * 2 * dim + (c >> 2) * 64 + (c & 3) * 8;
+        *reinterpret_cast<bf16x8*>(o) = hi;
+        *reinterpret_cast<bf16x8*>(o + 32) = lo;
+    }
+}
+
 // Lower bound of every query's final K-th score from a finished top-K of SOME of the rows: if that
 // list is full, its last score is reached by K rows, so the final K-th score cannot be lower.
 __global__ void tau_from_topk_kernel(const float* __restrict__ score, const int32_t* __restrict__ count, int n_queries,
@@ -404,6 +473,8 @@ __global__ void euclid_finish_kernel(float* score, const int32_t* count, const f
 struct rag_dense_s {
     float* rows = nullptr;
     float* row_norm2 = nullptr;
+    float* rows_split = nullptr;   // split image of the rows (rag_dense_enable_split), or null
+    DevBuf queries_split, tmp_score, tmp_row, tmp_count;
     bool owns_rows = false;
     int64_t n_rows = 0;
     int dim = 0;
@@ -478,6 +549,11 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
     if (!h) return RAG_OK;
     if (h->owns_rows && h->rows) (void)hipFree(h->rows);
     if (h->row_norm2) (void)hipFree(h->row_norm2);
+    if (h->rows_split) (void)hipFree(h->rows_split);
+    h->queries_split.release();
+    h->tmp_score.release();
+    h->tmp_row.release();
+    h->tmp_count.release();
     if (h->profiling) (void)rag_dense_profile(h, 0);
     h->scratch.release();
     h->cand.release();
@@ -488,6 +564,30 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
 }
 
 extern "C" int64_t rag_dense_rows(rag_dense_t h) { return h ? h->n_rows : -1; }
+
+extern "C" int rag_dense_enable_split(rag_dense_t h, int32_t enable) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_enable_split: null handle");
+    if (!enable) {
+        if (h->rows_split) (void)hipFree(h->rows_split);
+        h->rows_split = nullptr;
+        return RAG_OK;
+    }
+    RAG_REQUIRE(h->dim % 32 == 0, RAG_EINVAL, "rag_dense_enable_split: dim %d is not a multiple of 32", h->dim);
+    if (h->rows_split || h->n_rows == 0) return RAG_OK;
+    const size_t bytes = (size_t)h->n_rows * h->dim * sizeof(float);
+    hipError_t e = hipMalloc((void**)&h->rows_split, bytes);
+    if (e != hipSuccess) {
+        h->rows_split = nullptr;
+        rag_set_error("rag_dense_enable_split: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return RAG_ENOMEM;
+    }
+    const int64_t n8 = h->n_rows * (h->dim / 8);
+    split_rows_kernel<<<(unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1), 256>>>(h->rows, h->n_rows, h->dim,
+                                                                                         (bf16*)h->rows_split);
+    RAG_HIP_TRY(hipGetLastError());
+    RAG_HIP_TRY(hipDeviceSynchronize());
+    return RAG_OK;
+}
 
 extern "C" int rag_dense_profile(rag_dense_t h, int32_t enable) {
     RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_profile: null handle");
@@ -556,12 +656,13 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool pres
     p.cand = (uint2*)h->cand.p;
     p.cand_count = (int32_t*)h->cand_count.p;
 
-    auto kern = p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true> : dense_scan_kernel<WQ, TQ, WR, TR, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[p.euclid]) {
+    auto kern = p.split ? (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, true> : dense_scan_kernel<WQ, TQ, WR, TR, false, true>)
+                        : (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, false> : dense_scan_kernel<WQ, TQ, WR, TR, false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[2 * p.split + p.euclid]) {
         RAG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)Cfg::LDS_BYTES));
-        attr_set[p.euclid] = true;
+        attr_set[2 * p.split + p.euclid] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     RAG_HIP_TRY(hipGetLastError());
@@ -604,6 +705,18 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     }
     p.cap = (cap + 63) / 64 * 64;
     p.euclid = h->metric == RAG_METRIC_EUCLID;
+    p.split = 0;
+    if (h->rows_split && !getenv("RAG_DENSE_NO_SPLIT")) {
+        int rc0 = h->queries_split.ensure((size_t)n_queries * h->dim * sizeof(float));
+        if (rc0) return rc0;
+        const int64_t n8 = (int64_t)n_queries * (h->dim / 8);
+        split_rows_kernel<<<(unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1), 256, 0, stream>>>(
+            d_queries, n_queries, h->dim, (bf16*)h->queries_split.p);
+        RAG_HIP_TRY(hipGetLastError());
+        p.rows = h->rows_split;
+        p.queries = (const float*)h->queries_split.p;
+        p.split = 1;
+    }
     p.debug_row_mod = 0;
     p.fault = rag_fault_word();
     if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
@@ -640,6 +753,29 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     if (prof) {
         RAG_HIP_TRY(hipEventRecord(h->ev1[h->prof_n], stream));
         h->prof_n++;
+    }
+    if (p.split) {
+        // The split products chose the rows; their scores (good to about 1e-6) are replaced by plain fp32
+        // scores of the same rows and the list is put in order again, so callers that amplify score
+        // differences (min-max normalisation in weighted fusion) see fp32 accuracy.
+        const size_t nk = (size_t)n_queries * k;
+        if ((rc = h->tmp_score.ensure(nk * sizeof(float)))) return rc;
+        if ((rc = h->tmp_row.ensure(nk * sizeof(int64_t)))) return rc;
+        if ((rc = h->tmp_count.ensure((size_t)n_queries * sizeof(int32_t)))) return rc;
+        float* t_score = (float*)h->tmp_score.p;
+        int64_t* t_row = (int64_t*)h->tmp_row.p;
+        int32_t* t_count = (int32_t*)h->tmp_count.p;
+        rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, t_score, t_row,
+                                 t_count, p.fault, stream);
+        if (rc) return rc;
+        dense_rescore_kernel<<<(unsigned)ceil_div64((int64_t)nk, 4), 256, 0, stream>>>(
+            h->rows, d_queries, t_row, t_score, (int64_t)nk, k, h->dim, h->row_base, h->n_rows, p.euclid);
+        RAG_HIP_TRY(hipGetLastError());
+        ragmerge::ListF32Src src{t_score, t_row, t_count, 1, k, p.euclid ? 1 : 0};
+        hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT),
+                           0, stream, src, k, (int64_t)0, p.euclid ? 1 : 0, d_out_score, d_out_row, d_out_count, p.fault);
+        RAG_HIP_TRY(hipGetLastError());
+        return RAG_OK;
     }
     rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
                              d_out_row, d_out_count, p.fault, stream);

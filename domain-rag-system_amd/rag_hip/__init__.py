@@ -37,6 +37,7 @@ SIGNATURES = {
     'rag_dense_create': (_i32, [_vp, _i64, _i32, _i32, _i32, _i64, C.POINTER(_vp)]),
     'rag_dense_destroy': (_i32, [_vp]),
     'rag_dense_rows': (_i64, [_vp]),
+    'rag_dense_enable_split': (_i32, [_vp, _i32]),
     'rag_dense_profile': (_i32, [_vp, _i32]),
     'rag_dense_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_dense_search_dev': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -198,7 +199,10 @@ def _stream():
 class DenseIndex:
     """Resident [N x D] fp32 matrix with exact top-k search (rag_dense_* entry points)."""
 
-    def __init__(self, rows, metric='cosine', row_base=0, borrow=False):
+    def __init__(self, rows, metric='cosine', row_base=0, borrow=False, split='auto'):
+        """split: run searches as three bf16 matrix-core products of split operands (scores within ~1e-7 of
+        the fp32 products for unit vectors, a fifth of the matrix time, a second copy of the rows in HBM);
+        'auto' = whenever dim is a multiple of 32, False = exact fp32 FMA chains."""
         l = lib()
         self.metric = metric_code(metric)
         self._keep = None
@@ -224,6 +228,15 @@ class DenseIndex:
                   'rag_dense_create')
         self.n_rows, self.dim, self.row_base = int(n), int(d), int(row_base)
         self._h = h
+        self.split = False
+        if split is True and d % 32 != 0:
+            raise ValueError("split searches need a dimension that is a multiple of 32")
+        if split is True or (split == 'auto' and d % 32 == 0 and not os.environ.get('RAG_DENSE_EXACT')):
+            self.set_split(True)
+
+    def set_split(self, enable):
+        check(lib().rag_dense_enable_split(self._h, 1 if enable else 0), 'rag_dense_enable_split')
+        self.split = bool(enable)
 
     def close(self):
         if getattr(self, '_h', None):

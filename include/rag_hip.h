@@ -90,6 +90,14 @@ int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t met
                      int32_t mem_kind, int64_t row_base, rag_dense_t* out);
 int rag_dense_destroy(rag_dense_t h);
 int64_t rag_dense_rows(rag_dense_t h);
+/* enable != 0: keep a second image of the rows (same size) in which every value is split into bf16
+ * high and low parts, and run searches as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32
+ * accumulation (queries are split per search).  Those scores differ from the fp32 products by at most
+ * 2^-16 |row||query| (1e-7 to 1e-6 for unit vectors) and only choose the rows: the scores returned
+ * are plain fp32 scores of the chosen rows, in order.  A fifth of the matrix time.  dim must be a
+ * multiple of 32.
+ * enable == 0 drops the image: searches use exact fp32 FMA chains again (the default).          */
+int rag_dense_enable_split(rag_dense_t h, int32_t enable);
 /* Measurement aid (no counterpart in the reference): while enabled, every search records a
  * HIP event pair on the launch stream around its scan (the threshold pre-pass over a sample
  * of rows, when one runs, and the scan kernel; not the final merge), up to 256 searches;
