@@ -119,9 +119,12 @@ def build_shard(args, rank, world, dev, dist):
         lens = [torch.empty_like(clen) for _ in range(world)]
         dist.all_gather(lens, clen)
         sizes = [int(l.sum()) for l in lens]
-        toks = [torch.empty((s,), dtype=torch.int32, device=dev) for s in sizes]
-        dist.all_gather(toks, tok)
-        tok = torch.cat(toks)
+        longest = max(sizes)            # shards differ in length: gather equal-sized (padded) pieces
+        mine = torch.zeros((longest,), dtype=torch.int32, device=dev)
+        mine[:tok.shape[0]] = tok
+        toks = [torch.empty((longest,), dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.all_gather(toks, mine)
+        tok = torch.cat([t[:s] for t, s in zip(toks, sizes)])
         clen = torch.cat(lens)
         off = torch.zeros(n * world + 1, dtype=torch.int64, device=dev)
         off[1:] = torch.cumsum(clen, 0)
@@ -234,10 +237,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # rehearsal of the multi-rank code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+    rehearse = world > 1 and os.environ.get('RAG_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     import rag_hip
