@@ -241,6 +241,8 @@ def main():
     rehearse = world > 1 and os.environ.get('RAG_BENCH_REHEARSE') == '1'
     if rehearse:
         local = 0
+        import faulthandler                      # a rank that waits forever shows where
+        faulthandler.dump_traceback_later(100, repeat=True)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)

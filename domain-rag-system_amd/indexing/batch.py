@@ -18,6 +18,8 @@ equals the unsharded one.
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -59,6 +61,9 @@ class BatchSearcher:
         # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_sort_by_length = True
+        # sharded: RAG_SPLIT_EMBED=1 lets each rank embed a slice of the queries and all-gathers the slices
+        # (covered by the gloo test on the CPU; off by default until it has run over RCCL)
+        self.split_embed = os.environ.get('RAG_SPLIT_EMBED', '0') == '1'
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
             and next(cross_encoder.parameters()).dtype == torch.bfloat16)
@@ -89,6 +94,23 @@ class BatchSearcher:
     # ---- stages ----------------------------------------------------------------------
     @torch.no_grad()
     def embed(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """Query embeddings [B, dim].  Sharded: every rank has all the queries, so each embeds one slice of
+        them and the slices are all-gathered (B x dim floats) instead of every rank embedding all of them."""
+        b = ids.shape[0]
+        if self.world > 1 and self.split_embed and b >= self.world:
+            per = (b + self.world - 1) // self.world
+            lo, hi = min(b, self.rank * per), min(b, (self.rank + 1) * per)
+            mine = self._embed_local(ids[lo:hi].contiguous(), mask[lo:hi].contiguous()) if hi > lo else None
+            dim = mine.shape[1] if mine is not None else self._embed_local(ids[:1], mask[:1]).shape[1]
+            piece = torch.zeros((per, dim), dtype=torch.float32, device=ids.device)
+            if mine is not None:
+                piece[:hi - lo] = mine
+            gathered = torch.empty((self.world * per, dim), dtype=torch.float32, device=ids.device)
+            self.dist.all_gather_into_tensor(gathered, piece)
+            return gathered[:b].contiguous()
+        return self._embed_local(ids, mask)
+
+    def _embed_local(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         if getattr(self.bi_encoder.bert, 'native', False):
             # unpadded: queries differ a lot in length, and padding positions cost full GEMM rows
             p_ids, p_types, p_pos, cu, longest = self.bi_encoder.bert.pack(ids, mask)

@@ -72,6 +72,17 @@ def run_rank(rank, world, port, out_path, fusion='rrf'):
     ce_off = torch.arange(ids.shape[0] + 1, dtype=torch.int64) * 6
     out = s.search(ids, torch.ones_like(ids), torch.from_numpy(qterms), torch.from_numpy(qoff), int(qoff[-1]),
                    ce_tok, ce_off)
+    if world > 1:
+        # the optional exchange of query embeddings (each rank embeds a slice) must give the same answer
+        s.split_embed = True
+        again = s.search(ids, torch.ones_like(ids), torch.from_numpy(qterms), torch.from_numpy(qoff), int(qoff[-1]),
+                         ce_tok, ce_off)
+        for k, v in out.items():
+            if torch.is_tensor(v):
+                if v.dtype.is_floating_point:
+                    assert torch.allclose(v, again[k], atol=1e-5), k
+                else:
+                    assert torch.equal(v, again[k]), k
     if rank == 0:
         torch.save({k: v for k, v in out.items()}, out_path)
     if dist is not None:
