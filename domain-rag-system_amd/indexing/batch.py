@@ -238,6 +238,14 @@ class BatchSearcher:
         cu_all[1:] = torch.cumsum(plen, 0)
         cu_host = cu_all.cpu().numpy()                   # the one host copy of the stage
         budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
+        cb = self.cross_encoder.bert
+        if (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
+                and cb.config.hidden_size == 384 and not getattr(cb, 'fused_linear', False)):
+            # every GEMM of the layers is one of the library's own kernels, which take any row count: the
+            # coarse token grid (there for hipBLASLt's per-shape solutions) would only add padding rows
+            bucket = min(bucket, 128)
+        if os.environ.get('RAG_CE_TOKENS'):
+            budget = int(os.environ['RAG_CE_TOKENS'])
         p0 = 0
         while p0 < n_mine:
             # as many whole pairs as fit the token budget (a single pair always fits: budget >> max_len)
