@@ -11,6 +11,8 @@
 //  add_layernorm_kernel   LayerNorm(x + residual) in one pass, fp32 arithmetic, one wave per row.
 #include "common.h"
 
+#include <algorithm>
+
 #include <math.h>
 
 namespace {
@@ -20,7 +22,7 @@ typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int ATT_NT = 256;          // 4 waves; each takes 32-query blocks round-robin
+constexpr int ATT_NT = 256;          // at most 4 waves; each takes 32-query blocks round-robin
 constexpr float NEG_BIG = -1e30f;    // finite stand-in for -inf (keeps max/exp free of NaN)
 
 // 8-element vector access for the row kernels
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
     }
     // each thread moves 8 dims of two neighbouring keys, so the transposed image is written 4 bytes at a time
     typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += ATT_NT) {
+    for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += (int)blockDim.x) {
         const int key = (idx / (D / 8)) * 2, c8 = idx % (D / 8);
         bf16x8 k0, k1, v0, v1;
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
     }
     __syncthreads();
 
-    for (int qb = wave; qb * 32 < n_query_rows; qb += ATT_NT / 64) {
+    for (int qb = wave; qb * 32 < n_query_rows; qb += (int)(blockDim.x >> 6)) {
         const int q = qb * 32 + r;
         if (qb * 32 >= len) {
             // padding rows only: defined (zero) output, nothing to compute
@@ -705,6 +707,9 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
     const size_t lds = (size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2;
     const float scale = 1.4426950408889634f / sqrtf((float)head_dim);   // log2(e) / sqrt(D): the kernel works in base 2
     const unsigned grid = (unsigned)((int64_t)((n_seq + 7) / 8) * 8 * n_heads);
+    // a wave per 32-query block of the longest sequence, four at most: waves without a block of their own
+    // would only hold wave slots that other workgroups of the compute unit can use
+    const int att_nt = first_only ? ATT_NT : 64 * std::min(4, (seq_len + 31) / 32);
     if (dtype == RAG_DTYPE_F32) {
         const float scale32 = 1.0f / sqrtf((float)head_dim);
         if (head_dim == 32)
@@ -725,7 +730,7 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<32><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
+        attention_kernel<32><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
                                                             n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     } else {
         static size_t granted = 64 * 1024;
@@ -734,7 +739,7 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
                                             160 * 1024));
             granted = 160 * 1024;
         }
-        attention_kernel<64><<<grid, ATT_NT, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
+        attention_kernel<64><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
                                                             n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     }
     RAG_HIP_TRY(hipGetLastError());
