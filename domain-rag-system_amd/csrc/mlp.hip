@@ -157,8 +157,13 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     return gelu_tail(v, c, s, p);
 }
 
-template <bool PROJ>
+// MODE 0: the feed-forward block of x.  MODE 1 (PROJ): x1 = LN1(x + ctx Wo^T + bo) first, then the block of x1.
+// MODE 2: x1 = LN1(x + ctx) first, ctx being the finished attention-output projection (bias included): the
+// residual + LayerNorm pass between the projection and this kernel, done on the rows this kernel loads anyway.
+template <int MODE>
 __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
+    constexpr bool PROJ = MODE == 1;
+    constexpr bool PRE_LN = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ML_STAMP(tk0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,11 +211,11 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     const int last = n_chunks - 1;
     dma_w1(0, 0);
     dma_w1(min(1, last), 1);
-    if constexpr (!PROJ) dma_w2(0, 0);
+    if constexpr (!PROJ) dma_w2(0, 0);   // PROJ: the W2 buffers carry Wo first
     for (int i = tid; i < p.I; i += ML_NT) *reinterpret_cast<float*>(smem + ML_OFF_B1 + 4 * i) = (float)p.b1[i];
-    for (int i = tid; i < (PROJ ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, bf16
+    for (int i = tid; i < (PRE_LN ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, bf16
         const int vsel = i / (ML_HID / 8), piece = i % (ML_HID / 8);
-        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : vsel == 2 ? p.beta : vsel == 3 ? p.bo : vsel == 4 ? p.gamma1 : p.beta1;
+        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : vsel == 2 ? p.beta : vsel == 3 ? (PROJ ? p.bo : p.b2) : vsel == 4 ? p.gamma1 : p.beta1;
         *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (vsel * ML_HID + piece * 8)) =
             *reinterpret_cast<const bf16x8*>(src + piece * 8);
     }
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     // (PROJ: the rows of the attention output first; X is then computed below)
     bf16x8 xf[ML_KS];
     {
-        const bf16* xrow = (PROJ ? p.ctx : p.x) + tok_ld * ML_HID + 8 * h;
+        const bf16* xrow = (PRE_LN ? p.ctx : p.x) + tok_ld * ML_HID + 8 * h;
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
     }
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) yacc[m][i] = 0.f;
 
-    if constexpr (PROJ) {
+    if constexpr (PRE_LN) {
+      if constexpr (PROJ) {
         // ---- attention-output projection and its LayerNorm:  X = LN1(x_in + ctx Wo^T + bo).
         // Y1^T[feature][token] = Wo . ctx^T into the same twelve accumulator tiles, Wo streamed through
         // the two W2 buffers in 12 slices of 32 input columns (the W2 image shape: 24 MFMAs per slice,
@@ -305,7 +311,10 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         };
         unrolled(std::make_integer_sequence<int, ML_HID / ML_C>{}, slice);
         dma_w2(0, 0);                                         // both W2 buffers are free again
+      }
         // bias, residual, LayerNorm; the result replaces the ctx fragments in xf
+        // (MODE 2: the accumulator registers only serve as the fp32 copy of the row)
+        if constexpr (!PROJ) __syncthreads();                 // gamma1 | beta1 were staged by other threads
         const unsigned char* v1 = smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (3 * ML_HID) + 16 * h;   // bo | gamma1 | beta1
         const bf16* xin = p.x + tok_ld * ML_HID + 8 * h;
         float sum = 0.f;
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
             const bf16x8 bb = *reinterpret_cast<const bf16x8*>(v1 + 32 * t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xr[j];
+                const float v = PROJ ? yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xr[j]
+                                     : (float)xf[t][j] + (float)xr[j];
                 yacc[t >> 1][8 * (t & 1) + j] = v;
                 sum += v;
             }
@@ -692,23 +702,26 @@ struct MlpProfile {
 };
 MlpProfile g_prof;
 
-int launch_mlp(const MlpParams& p, bool proj, hipStream_t stream, const char* who) {
+int launch_mlp(const MlpParams& p, int mode, hipStream_t stream, const char* who) {
     RAG_REQUIRE(ceil_div64(p.M, ML_BM) < (1ll << 31), RAG_ELIMIT, "%s: too many rows", who);
     const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)p.I + 6 * ML_HID * 2;
     static bool attr_set = false;
     if (!attr_set) {
         const int max_lds = ML_OFF_B1 + 4 * ML_MAX_I + 6 * ML_HID * 2;
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
         attr_set = true;
     }
     const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
     const bool timed = g_prof.on && g_prof.n < MlpProfile::RING;
     if (timed) RAG_HIP_TRY(hipEventRecord(g_prof.ev0[g_prof.n], stream));
-    if (proj)
-        hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, dim3(ML_NT), lds_bytes, stream, p);
+    if (mode == 1)
+        hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(ML_NT), lds_bytes, stream, p);
+    else if (mode == 2)
+        hipLaunchKernelGGL(mlp_fused_kernel<2>, grid, dim3(ML_NT), lds_bytes, stream, p);
     else
-        hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, dim3(ML_NT), lds_bytes, stream, p);
+        hipLaunchKernelGGL(mlp_fused_kernel<0>, grid, dim3(ML_NT), lds_bytes, stream, p);
     RAG_HIP_TRY(hipGetLastError());
     if (timed) {
         RAG_HIP_TRY(hipEventRecord(g_prof.ev1[g_prof.n], stream));
@@ -735,7 +748,7 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
     p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
     p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.y = (bf16*)d_y;
     p.M = m; p.I = intermediate; p.eps = eps;
-    return launch_mlp(p, false, (hipStream_t)stream_, "rag_enc_mlp");
+    return launch_mlp(p, 0, (hipStream_t)stream_, "rag_enc_mlp");
 }
 
 extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_wo, const void* d_bo,
@@ -760,7 +773,30 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
     p.M = m; p.I = intermediate; p.eps = eps;
     p.ctx = (const bf16*)d_ctx; p.wo = (const bf16*)d_wo; p.bo = (const bf16*)d_bo;
     p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
-    return launch_mlp(p, true, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
+    return launch_mlp(p, 1, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
+}
+
+extern "C" int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const void* d_gamma1, const void* d_beta1,
+                                    const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
+                                    const void* d_gamma2, const void* d_beta2, float eps, int64_t m, int32_t hidden,
+                                    int32_t intermediate, int32_t dtype, void* d_y, void* stream_) {
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_norm_mlp: bf16 only");
+    RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_norm_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
+    RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
+                "rag_enc_norm_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I,
+                intermediate);
+    RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_norm_mlp: negative row count");
+    if (m == 0) return RAG_OK;
+    RAG_REQUIRE(d_proj && d_x && d_gamma1 && d_beta1 && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma2 && d_beta2 && d_y,
+                RAG_EINVAL, "rag_enc_norm_mlp: null pointer");
+    RAG_REQUIRE(aligned16({d_proj, d_x, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
+                "rag_enc_norm_mlp: pointers must be 16-byte aligned");
+    MlpParams p = {};
+    p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
+    p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma2; p.beta = (const bf16*)d_beta2; p.y = (bf16*)d_y;
+    p.M = m; p.I = intermediate; p.eps = eps;
+    p.ctx = (const bf16*)d_proj; p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
+    return launch_mlp(p, 2, (hipStream_t)stream_, "rag_enc_norm_mlp");
 }
 
 extern "C" int rag_enc_mlp_profile(int32_t enable) {

@@ -108,6 +108,7 @@ class BertEncoder(nn.Module):
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
+        self.fused_norm_mlp = False  # ... with the residual + LayerNorm in front of it in the same kernel (rag_enc_norm_mlp_dev): no faster
         self.fused_tail = False      # ... and the attention-output projection + LayerNorm in the same kernel
 
     @staticmethod
@@ -183,6 +184,12 @@ class BertEncoder(nn.Module):
             if self._layer_tail_fused(l, x):
                 x = self._layer_tail(l, ctx, x)
                 continue
+            if self._norm_mlp_fused(l, x, ctx):
+                # output projection, then residual + LayerNorm + feed-forward block in one kernel
+                x = rag_hip.enc_norm_mlp_dev(self._linear(l.attn_out, ctx), x.contiguous(), l.attn_norm.weight,
+                                             l.attn_norm.bias, l.ffn_in.weight, l.ffn_in.bias, l.ffn_out.weight,
+                                             l.ffn_out.bias, l.ffn_norm.weight, l.ffn_norm.bias, l.ffn_norm.eps)
+                continue
             if self.fused_linear and rag_hip.enc_linear_supported(ctx, l.attn_out.weight) and x.shape[1] == 384:
                 # output projection with bias + residual + LayerNorm in the GEMM epilogue
                 x = rag_hip.enc_linear_dev(ctx, l.attn_out.weight, l.attn_out.bias,
@@ -217,6 +224,13 @@ class BertEncoder(nn.Module):
         return (self.fused_mlp and self.fused_tail and l.attn_norm.eps == l.ffn_norm.eps
                 and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight)
                 and l.attn_out.weight.dtype == torch.bfloat16)
+
+    def _norm_mlp_fused(self, l, x, ctx):
+        import rag_hip
+        return (self.fused_mlp and self.fused_norm_mlp and self.native_linear and ctx.dim() == 2
+                and l.attn_norm.eps == l.ffn_norm.eps
+                and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight)
+                and rag_hip.enc_linear384_supported(ctx, l.attn_out.weight))
 
     def _layer_tail(self, l, ctx, x):
         """Everything after self-attention (output projection, residual + LayerNorm, feed-forward

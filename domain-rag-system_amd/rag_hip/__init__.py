@@ -78,6 +78,7 @@ SIGNATURES = {
     'rag_enc_mlp_profile': (_i32, [_i32]),
     'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_norm_mlp_dev': (_i32, [_vp] * 10 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
     'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
     'rag_enc_bias_act_split_bf16x3_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
@@ -911,6 +912,27 @@ def enc_attn_out_mlp_dev(ctx, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, 
                                          _ptr(beta1, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf),
                                          _ptr(gamma2, bf), _ptr(beta2, bf), float(eps), m, hid, inter, DTYPE_BF16,
                                          _ptr(y), _stream()), 'rag_enc_attn_out_mlp_dev')
+    return y
+
+
+def enc_norm_mlp_dev(proj, x, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps=1e-12):
+    """A BERT layer after its attention-output projection in one kernel (rag_enc_norm_mlp_dev):
+    x1 = LN(x + proj), y = LN(x1 + GELU(x1 @ w1.T + b1) @ w2.T + b2); proj, x [M, 384] bf16."""
+    import torch
+    m, hid = x.shape
+    inter = w1.shape[0]
+    if tuple(proj.shape) != (m, hid):
+        raise ValueError("proj must have the shape of x")
+    if tuple(w1.shape) != (inter, hid) or tuple(w2.shape) != (hid, inter) or tuple(b1.shape) != (inter,):
+        raise ValueError("w1 must be [I, H], w2 [H, I] and b1 [I]")
+    for v in (gamma1, beta1, b2, gamma2, beta2):
+        if tuple(v.shape) != (hid,):
+            raise ValueError("b2 and the LayerNorm vectors must be [H]")
+    y = torch.empty_like(x)
+    bf = torch.bfloat16
+    check(lib().rag_enc_norm_mlp_dev(_ptr(proj, bf), _ptr(x, bf), _ptr(gamma1, bf), _ptr(beta1, bf), _ptr(w1, bf),
+                                     _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma2, bf), _ptr(beta2, bf),
+                                     float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()), 'rag_enc_norm_mlp_dev')
     return y
 
 

@@ -347,6 +347,16 @@ int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_w
                              const void* d_gamma2, const void* d_beta2, float eps, int64_t m,
                              int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y,
                              void* stream);
+/* The same block with only the residual + LayerNorm in front of it:
+ *   x1 = LayerNorm(x + proj) * gamma1 + beta1,   y = LayerNorm(x1 + W2 GELU(W1 x1 + b1) + b2) * gamma2 + beta2
+ * where proj is the finished attention-output projection (bias included, e.g. from
+ * rag_enc_linear384_dev): BertSelfOutput's LayerNorm and BertIntermediate/BertOutput of a layer
+ * (transformers, reached through CrossEncoder.predict, reference src/reranker/rerank.py:83) without
+ * the separate pass over the activations for the first LayerNorm.  Same limits as rag_enc_mlp_dev. */
+int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const void* d_gamma1, const void* d_beta1,
+                         const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
+                         const void* d_gamma2, const void* d_beta2, float eps, int64_t m, int32_t hidden,
+                         int32_t intermediate, int32_t dtype, void* d_y, void* stream);
 /* y[m][n] = sum_k x[m][k] w[n][k] + bias[n] for 384-wide inputs (bf16, fp32 accumulation): the
  * q|k|v and attention-output projections of the cross-encoder layers (same reference path as
  * rag_enc_mlp_dev).  x [m][384], w [n][384] as nn.Linear stores it, n a multiple of 32; y must not

@@ -75,6 +75,32 @@ def test_attention_output_and_mlp_block_matches_exact(m, inter):
     assert float(err.mean()) <= float((yu.double() - ref).abs().mean()) * 1.1 + 1e-4
 
 
+@pytest.mark.parametrize('m,inter', [(1000, 1536), (128, 1536), (1, 1536), (129, 64), (4097, 1536)])
+def test_residual_layernorm_and_mlp_block_in_one_kernel(m, inter):
+    """LN(x + proj) in front of the feed-forward block, in its kernel: against the residual+LayerNorm kernel
+    followed by the feed-forward kernel (nearly always the same bf16 values: the two LayerNorms sum their
+    rows in different orders) and against fp64."""
+    import rag_hip
+    x, w1, b1, w2, b2, gamma2, beta2 = _layer(m, inter, 13 * m + inter)
+    dev, bf = x.device, torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(3 * m + inter)
+    proj = torch.randn((m, 384), generator=g, device=dev).to(bf)
+    gamma1 = (1 + 0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    beta1 = (0.1 * torch.randn((384,), generator=g, device=dev)).to(bf)
+    y = rag_hip.enc_norm_mlp_dev(proj, x, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, 1e-12)
+    x1u = rag_hip.enc_add_layernorm_dev(proj, x, gamma1, beta1, 1e-12)
+    yu = rag_hip.enc_mlp_dev(x1u, w1, b1, w2, b2, gamma2, beta2, 1e-12)
+    assert float((y.float() - yu.float()).abs().mean()) < 2e-3
+    assert float((y == yu).float().mean()) > 0.9
+    d = torch.float64
+    x1 = torch.nn.functional.layer_norm(x.to(d) + proj.to(d), (384,), gamma1.to(d), beta1.to(d), 1e-12)
+    ref = _exact(x1.to(bf), w1, b1, w2, b2, gamma2, beta2)
+    err = (y.double() - ref).abs()
+    assert float(err.mean()) < 6e-3
+    assert float(err.max()) < 8e-2
+    assert float(err.mean()) <= float((yu.double() - ref).abs().mean()) * 1.1 + 1e-4
+
+
 @pytest.mark.parametrize('m,n', [(1000, 1152), (128, 1152), (1, 32), (129, 64), (4097, 1152), (77, 384)])
 def test_linear384_matches_exact(m, n):
     import rag_hip
