@@ -61,9 +61,9 @@ class BatchSearcher:
         # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_sort_by_length = True
-        # sharded: RAG_SPLIT_EMBED=1 lets each rank embed a slice of the queries and all-gathers the slices
-        # (covered by the gloo test on the CPU; off by default until it has run over RCCL)
-        self.split_embed = os.environ.get('RAG_SPLIT_EMBED', '0') == '1'
+        # sharded over RCCL: each rank embeds a slice of the queries and the slices are all-gathered
+        # (RAG_SPLIT_EMBED=0: every rank embeds all of them; =1 forces the exchange on other backends)
+        self.split_embed = False
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
             and next(cross_encoder.parameters()).dtype == torch.bfloat16)
@@ -71,6 +71,9 @@ class BatchSearcher:
         self.dist = dist                                  # torch.distributed module when sharded
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        if dist is not None:
+            want = os.environ.get('RAG_SPLIT_EMBED')
+            self.split_embed = want == '1' or (want != '0' and dist.get_backend() == 'nccl')
         self.times = StageTimes()
         self.timing = False
         self._side_stream = None
