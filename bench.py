@@ -42,7 +42,14 @@ def parse():
     ap.add_argument('--vocab', type=int, default=200_000)
     ap.add_argument('--top-k', type=int, default=5)
     ap.add_argument('--rerank-top-n', type=int, default=50)
-    ap.add_argument('--ce-dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--ce-dtype', default='fp32', choices=['fp32', 'bf16', 'fp32-torch'],
+                    help="cross-encoder arithmetic: 'fp32' = float32 weights and activations, GEMMs and attention as "
+                         "split-bf16 matrix-core products with fp32 accumulation (the reference's precision, default); "
+                         "'bf16' = the bfloat16 kernels (faster, does not hold the fp32 order); 'fp32-torch' = plain PyTorch ops")
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary measurements (rerank_top_n=30, bf16 cross-encoder, batch sweep, host-buffer run) '
+                         'and the precision check: for profiler runs')
+    ap.add_argument('--extra-steps', type=int, default=4, help='timed steps of each secondary measurement')
     ap.add_argument('--ce-pairs-per-batch', type=int, default=16384,
                     help='pairs per cross-encoder forward (an unpadded token stream when the model runs the librag_hip kernels)')
     ap.add_argument('--tune-gemms', default=None, metavar='FILE',
@@ -268,17 +275,30 @@ def main():
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
     bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev, native=not args.embed_torch_ops,
                                split_gemm=not args.embed_fp32_gemm)
-    ce_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.ce_dtype]
-    ce, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=ce_dtype,
-                               native=ce_dtype == torch.bfloat16 and not args.ce_torch_ops)
-    ce.bert.fused_linear = bool(args.ce_fused_linear)
-    ce.bert.fused_mlp = not args.ce_library_mlp
-    ce.bert.native_linear = not args.ce_library_linear
-    ce.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
-    ce.bert.fused_tail = bool(args.ce_fused_attn_out)
-    searcher = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce,
-                             chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k,
-                             rerank_top_n=args.rerank_top_n, ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist)
+    def load_ce(kind):
+        """The cross-encoder in one of the three arithmetic forms of --ce-dtype."""
+        if kind == 'bf16':
+            m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.bfloat16,
+                                      native=not args.ce_torch_ops)
+        elif kind == 'fp32':
+            m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32, native=True,
+                                      split_gemm=True)
+        else:
+            m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32)
+        m.bert.fused_linear = bool(args.ce_fused_linear)
+        m.bert.fused_mlp = not args.ce_library_mlp
+        m.bert.native_linear = not args.ce_library_linear
+        m.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
+        m.bert.fused_tail = bool(args.ce_fused_attn_out)
+        return m
+
+    def make_searcher(model, top_n, with_dist=True):
+        return BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=model,
+                             chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=top_n,
+                             ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist if with_dist else None)
+
+    ce = load_ce(args.ce_dtype)
+    searcher = make_searcher(ce, args.rerank_top_n)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
     if args.tune_gemms and searcher.ce_packed:
@@ -388,8 +408,12 @@ def main():
         'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s (cross-encoder forward) / %s' % (
-            args.ce_dtype, 'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else
+        'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s / %s' % (
+            {'fp32': 'f32 cross-encoder forward with GEMMs and attention as 3 split-bf16 MFMA products, fp32 accumulation '
+                     '(logits within 2e-6 of the fp32 forward)',
+             'bf16': 'bf16 cross-encoder forward (does NOT hold the fp32 order: see precision_check)',
+             'fp32-torch': 'f32 cross-encoder forward (PyTorch ops)'}[args.ce_dtype],
+            'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else
             'f32 embedder forward with GEMMs as 3 split-bf16 MFMA products, fp32 accumulation (cosine within 1e-5 of fp32)'),
         'data': 'synthetic (seeded random unit vectors, Zipf postings, random token ids, random-init weights)',
         'config': {'workload': '%dM x %d corpus%s, hybrid vector+BM25, RRF, MiniLM-L6 cross-encoder rerank_top_n=%d, '
@@ -405,16 +429,97 @@ def main():
         'roofline': roofline_ff if roofline_ff is not None else roofline,
         'roofline_dense_scan': roofline,
     }
+    off_h = tok_h = None
+
+    def search_with(srch, q):
+        o = srch.search(*as_args(q))
+        torch.cuda.synchronize()
+        return o
+
+    def time_steps(srch, batch_list, n_warm=1):
+        """queries/sec and ms per step of `srch` over batch_list (after n_warm untimed batches of it)."""
+        for q in batch_list[:n_warm]:
+            srch.search(*as_args(q))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for q in batch_list:
+            srch.search(*as_args(q))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        nq = sum(int(q['ids'].shape[0]) for q in batch_list)
+        return round(nq / el, 2), round(el / len(batch_list) * 1e3, 3)
+
+    if world == 1 and not args.no_extras:
+        # (1) the TIMED searcher against a plain PyTorch float32 cross-encoder (what CrossEncoder.predict computes,
+        # reference src/reranker/rerank.py:79-84) on every query of batch 0: final top-k ids, in order.  A query is
+        # excused only if two of the float32 logits that decide its top-k lie closer than eps (float32 round-off of
+        # two different summation orders cannot be told apart there).
+        eps = 2e-5
+        o_timed = search_with(searcher, queries[0])
+        ce_ref = load_ce('fp32-torch')
+        o_ref = search_with(make_searcher(ce_ref, t), queries[0])
+        k = args.top_k
+        ref_sorted = torch.sort(o_ref['logits'].double(), dim=1, descending=True).values
+        gap = (ref_sorted[:, :k] - ref_sorted[:, 1:k + 1]).min(dim=1).values
+        same = (o_timed['rows'] == o_ref['rows']).all(dim=1)
+        fused_same = bool((o_timed['fused_row'] == o_ref['fused_row']).all())
+        err = float((o_timed['logits'].double() - o_ref['logits'].double()).abs().max())
+        result['precision_check'] = {
+            'reference': 'plain PyTorch float32 cross-encoder forward on the same fused candidates',
+            'queries': int(same.numel()), 'top_k_ids_identical': int(same.sum()),
+            'differing_with_fp32_gap_below_eps': int((~same & (gap < eps)).sum()),
+            'differing_unexcused': int((~same & (gap >= eps)).sum()), 'eps': eps,
+            'fused_candidates_identical': fused_same, 'max_abs_logit_error': err,
+            'median_deciding_gap_fp32': float(gap.median())}
+        del ce_ref
+
+        # (2) secondary measurements, each a few timed steps of the same batches
+        nx = max(1, min(args.extra_steps, len(queries)))
+        extra = {}
+        v, ms = time_steps(make_searcher(ce, 30), queries[:nx])
+        extra['rerank_top_n_30'] = {'value': v, 'ms_per_step': ms, 'unit': 'queries/sec',
+                                    'note': 'same path with --rerank_top_n 30 (60 entries per list, 30 pairs per query)'}
+        other = 'bf16' if args.ce_dtype != 'bf16' else 'fp32'
+        ce_other = load_ce(other)
+        s_other = make_searcher(ce_other, t)
+        v, ms = time_steps(s_other, queries[:nx])
+        o_other = search_with(s_other, queries[0])
+        same_o = (o_other['rows'] == o_ref['rows']).all(dim=1)
+        extra['cross_encoder_' + other] = {
+            'value': v, 'ms_per_step': ms, 'unit': 'queries/sec',
+            'top_k_ids_identical_to_fp32': '%d/%d' % (int(same_o.sum()), int(same_o.numel())),
+            'max_abs_logit_error': float((o_other['logits'].double() - o_ref['logits'].double()).abs().max())}
+        del ce_other, s_other
+        sweep = []
+        for bsz in (1, 32, 256):
+            sub = argparse.Namespace(**{**vars(args), 'batch': bsz})
+            qs = make_queries(sub, nx + 1, dev, seed=300 + bsz)
+            v, ms = time_steps(searcher, qs[1:], n_warm=1)
+            sweep.append({'batch': bsz, 'latency_ms': ms, 'value': v})
+        extra['batch_sweep'] = sweep
+        # the same step when the boundary hands over HOST buffers: queries copied in from pinned memory and the
+        # result lists copied back inside the timed region
+        pin = lambda x: x.cpu().pin_memory()
+        hq = [{k2: pin(q[k2]) for k2 in ('ids', 'mask', 'qterms', 'qoff', 'ce_tok', 'ce_off')} | {'n_terms': q['n_terms']}
+              for q in queries[:nx]]
+        sink = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for q in hq:
+            dq = {k2: (v2.to(dev, non_blocking=True) if hasattr(v2, 'to') else v2) for k2, v2 in q.items()}
+            o = searcher.search(*as_args(dq))
+            sink = [o[k2].to('cpu', non_blocking=True) for k2 in ('rows', 'scores', 'rerank_score', 'count')]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        extra['host_buffers'] = {'value': round(args.batch * len(hq) / el, 2), 'ms_per_step': round(el / len(hq) * 1e3, 3),
+                                 'note': 'H2D of the query tensors and D2H of rows / scores inside the timed region'}
+        result['secondary'] = extra
+
     if args.cpu_queries > 0 and world == 1:
         bi_cpu, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', 'cpu')
         ce_cpu, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', 'cpu')
-        # GPU results for the sample, cross-encoder in fp32 like the host run
-        ce32, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32)
-        s32 = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=ce32,
-                            chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=t)
-        o = s32.search(queries[0]['ids'], queries[0]['mask'], queries[0]['qterms'], queries[0]['qoff'],
-                       queries[0]['n_terms'], queries[0]['ce_tok'], queries[0]['ce_off'])
-        torch.cuda.synchronize()
+        # the oracle's ids against those of the TIMED searcher (same object, same kernels) on batch 0
+        o = search_with(searcher, queries[0])
         off_h = off.cpu().numpy()
         tok_h = tok.cpu().numpy()
         gpu_out = {'fused_row': o['fused_row'].cpu().numpy(), 'rows': o['rows'].cpu().numpy(),

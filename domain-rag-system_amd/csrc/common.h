@@ -63,6 +63,16 @@ struct DevBuf {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Raise a kernel's dynamic-LDS limit to `bytes` on the CURRENT device (the attribute belongs to the
+// device's copy of the function, so the grants are kept per device and kernel; a process may drive
+// several GPUs).  Cheap when already granted.  Returns RAG_OK or RAG_EHIP (error text set).
+int rag_grant_dyn_lds(const void* kernel, size_t bytes);
+#define RAG_GRANT_LDS(kernel, bytes)                                                   \
+    do {                                                                               \
+        int _rc = rag_grant_dyn_lds((const void*)(kernel), (size_t)(bytes));            \
+        if (_rc != RAG_OK) return _rc;                                                 \
+    } while (0)
+
 // Device word of the current device that collects RAG_FAULT_* bits (null if it could not be
 // allocated).  Kernels receive it as an argument; a kernel that finds an index read from
 // device data outside its array sets a bit there and carries on with a safe value instead

@@ -658,12 +658,7 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool pres
 
     auto kern = p.split ? (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, true> : dense_scan_kernel<WQ, TQ, WR, TR, false, true>)
                         : (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, false> : dense_scan_kernel<WQ, TQ, WR, TR, false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[2 * p.split + p.euclid]) {
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)Cfg::LDS_BYTES));
-        attr_set[2 * p.split + p.euclid] = true;
-    }
+    RAG_GRANT_LDS(kern, Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
     RAG_HIP_TRY(hipGetLastError());
     h->last_strips = p.n_strips;

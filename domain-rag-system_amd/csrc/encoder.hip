@@ -278,6 +278,223 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
     }
 }
 
+// fp32-equivalent attention on the bf16 matrix cores, for the float32 cross-encoder forward (the
+// reference's CrossEncoder.predict runs in float32, src/reranker/rerank.py:79-84).  Same structure as
+// attention_kernel (one workgroup per (sequence, head), keys row-major and values transposed in LDS,
+// S^T = K Q^T with a query per lane, probabilities fed back as the B operand of O^T += V^T P^T), with
+// every operand split into bf16 high and low parts, x = hi + lo, and every product taken as
+// hi.hi + lo.hi + hi.lo with fp32 accumulation (the dropped lo.lo term is below 2^-17 of the
+// product).  Input is the fp32 q|k|v projection WITHOUT its bias (added here while staging, so the
+// GEMM output needs no bias pass); output is the attention result already split for the output
+// projection's GEMM: row = [hi | hi | lo], 3 * H bf16 (the left operand of [w_hi ; w_lo ; w_hi]).
+// Packed batches only (cu_seqlens).
+template <int D>
+__global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float* __restrict__ qkv,
+                                                                    const float* __restrict__ bias,
+                                                                    const int32_t* __restrict__ cu, int64_t total_tokens,
+                                                                    int n_seq, int S_max, int NH, float scale,
+                                                                    int first_only, bf16* __restrict__ out,
+                                                                    uint32_t* fault) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KROW = D + 8;
+    constexpr int DT = D / 32;
+    constexpr int KC = D / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int jb = blockIdx.x >> 3;
+    const int head = jb % NH;
+    const int seq = (jb / NH) * 8 + (blockIdx.x & 7);    // a sequence's heads share an XCD (see attention_kernel)
+    if (seq >= n_seq) return;
+    const int H = NH * D;
+    const size_t tok = (size_t)3 * H;
+    const int64_t first = cu[seq];
+    const int64_t n = (int64_t)cu[seq + 1] - first;
+    if (first < 0 || n < 0 || n > S_max || first + n > total_tokens) {
+        if (threadIdx.x == 0) rag_flag(fault, RAG_FAULT_SEGMENT);
+        return;
+    }
+    const int len = (int)n;
+    const float* base = qkv + (size_t)first * tok + head * D;
+    const float* bq = bias != nullptr ? bias + head * D : nullptr;
+    bf16* obase = (first_only ? out + (size_t)seq * tok : out + (size_t)first * tok) + head * D;
+    const int kpad = (len + 31) & ~31;
+    const int VROW = kpad + 4;
+    bf16* Kh = reinterpret_cast<bf16*>(smem);
+    bf16* Kl = Kh + (size_t)kpad * KROW;
+    bf16* Vh = Kl + (size_t)kpad * KROW;
+    bf16* Vl = Vh + (size_t)D * VROW;
+    const int n_query_rows = first_only ? min(1, len) : len;
+
+    // eight consecutive fp32 values (+ bias) -> bf16 high and low parts
+    auto load8 = [&](const float* p, const float* b, bool live, bf16x8& hi, bf16x8& lo) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            if (b != nullptr) {
+                const float4 ba = *reinterpret_cast<const float4*>(b), bc = *reinterpret_cast<const float4*>(b + 4);
+                v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w; v[4] += bc.x; v[5] += bc.y; v[6] += bc.z; v[7] += bc.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (bf16)v[j];
+            lo[j] = (bf16)(v[j] - (float)hi[j]);
+        }
+    };
+    auto load_q = [&](int q, bf16x8* qh, bf16x8* ql) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            load8(base + (size_t)q * tok + 16 * c + 8 * h, bq != nullptr ? bq + 16 * c + 8 * h : nullptr,
+                  q < n_query_rows, qh[c], ql[c]);
+    };
+    bf16x8 qh[KC], ql[KC];
+    load_q(wave * 32 + r, qh, ql);
+
+    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += (int)blockDim.x) {
+        const int key = (idx / (D / 8)) * 2, c8 = idx % (D / 8);
+        const float* p = base + (size_t)key * tok + c8 * 8;
+        const float* bk = bq != nullptr ? bq + H + c8 * 8 : nullptr;
+        const float* bv = bq != nullptr ? bq + 2 * H + c8 * 8 : nullptr;
+        bf16x8 k0h, k0l, k1h, k1l, v0h, v0l, v1h, v1l;
+        load8(p + H, bk, key < len, k0h, k0l);
+        load8(p + 2 * H, bv, key < len, v0h, v0l);
+        load8(p + tok + H, bk, key + 1 < len, k1h, k1l);
+        load8(p + tok + 2 * H, bv, key + 1 < len, v1h, v1l);
+        *reinterpret_cast<bf16x8*>(Kh + key * KROW + c8 * 8) = k0h;
+        *reinterpret_cast<bf16x8*>(Kl + key * KROW + c8 * 8) = k0l;
+        *reinterpret_cast<bf16x8*>(Kh + (key + 1) * KROW + c8 * 8) = k1h;
+        *reinterpret_cast<bf16x8*>(Kl + (key + 1) * KROW + c8 * 8) = k1l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16x2 ph, pl;
+            ph[0] = v0h[j]; ph[1] = v1h[j];
+            pl[0] = v0l[j]; pl[1] = v1l[j];
+            *reinterpret_cast<bf16x2*>(Vh + (c8 * 8 + j) * VROW + key) = ph;
+            *reinterpret_cast<bf16x2*>(Vl + (c8 * 8 + j) * VROW + key) = pl;
+        }
+    }
+    __syncthreads();
+
+    for (int qb = wave; qb * 32 < n_query_rows; qb += (int)(blockDim.x >> 6)) {
+        const int q = qb * 32 + r;
+        if (qb != wave) load_q(q, qh, ql);
+        float m_run = NEG_BIG, l_run = 0.f;
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+
+        for (int kb = 0; kb < kpad; kb += 32) {
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Kh + (kb + r) * KROW + 16 * c + 8 * h);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (kb + r) * KROW + 16 * c + 8 * h);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+            }
+            float mx = NEG_BIG;
+            if (kb + 32 > len) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    s[i] = key < len ? s[i] * scale : NEG_BIG;
+                    mx = fmaxf(mx, s[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[i] *= scale;
+                    mx = fmaxf(mx, s[i]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[i] = exp2f(s[i] - m_new);
+                sum += s[i];
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            if (kb > 0) {
+                const float alpha = exp2f(m_run - m_new);
+                l_run = l_run * alpha + sum;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            } else {
+                l_run = sum;
+            }
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 pbh, pbl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pbh[j] = (bf16)s[8 * t + j];
+                    pbl[j] = (bf16)(s[8 * t + j] - (float)pbh[j]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const size_t vo = (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
+                    const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(Vh + vo), h1 = *reinterpret_cast<const bf16x4*>(Vh + vo + 8);
+                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(Vl + vo), l1 = *reinterpret_cast<const bf16x4*>(Vl + vo + 8);
+                    bf16x8 avh, avl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { avh[j] = h0[j]; avh[4 + j] = h1[j]; avl[j] = l0[j]; avl[4 + j] = l1[j]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, pbh, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, pbl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, pbh, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        // a lane holds d = 8g + 4h + j of its query's row; the two lanes of a query swap half of their groups so
+        // that each owns runs of eight consecutive d (lower: 0..7, 16..23; upper: 8..15, 24..31): 16-byte stores
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float grp[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) grp[g][j] = o[dt][4 * g + j] * inv;
+            float run[2][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float got0 = __shfl_xor(h ? grp[0][j] : grp[1][j], 32, 64);
+                const float got1 = __shfl_xor(h ? grp[2][j] : grp[3][j], 32, 64);
+                run[0][j] = h ? got0 : grp[0][j];
+                run[0][4 + j] = h ? grp[1][j] : got0;
+                run[1][j] = h ? got1 : grp[2][j];
+                run[1][4 + j] = h ? grp[3][j] : got1;
+            }
+            if (q < n_query_rows) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        hi[j] = (bf16)run[u][j];
+                        lo[j] = (bf16)(run[u][j] - (float)hi[j]);
+                    }
+                    bf16* dst = obase + (size_t)q * tok + dt * 32 + 8 * h + 16 * u;
+                    *reinterpret_cast<bf16x8*>(dst) = hi;
+                    *reinterpret_cast<bf16x8*>(dst + H) = hi;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * H) = lo;
+                }
+            }
+        }
+    }
+}
+
 // fp32 attention for the bi-encoder (its embeddings must hold 1e-4 on cosine scores, so its
 // forward stays in fp32): one wave per (sequence, head).  Queries are short (a dozen tokens), so a lane
 // per query row would leave most of the wave idle: the wave takes 16 query rows at a time and the four
@@ -688,6 +905,39 @@ extern "C" int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32
                             d_out, stream_, 1);
 }
 
+extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
+                                           int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                           int32_t head_dim, int32_t first_only, void* d_out, void* stream_) {
+    RAG_REQUIRE(n_seq >= 0 && max_seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention_split: bad sizes");
+    RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention_split: head_dim must be 32 or 64 (got %d)",
+                head_dim);
+    RAG_REQUIRE(total_tokens >= 0 && total_tokens < (1ll << 31), RAG_ELIMIT, "rag_enc_attention_split: bad token count");
+    if (n_seq == 0) return RAG_OK;
+    RAG_REQUIRE(d_qkv && d_cu_seqlens && d_out, RAG_EINVAL, "rag_enc_attention_split: null pointer");
+    RAG_REQUIRE(reinterpret_cast<uintptr_t>(d_qkv) % 16 == 0 && reinterpret_cast<uintptr_t>(d_bias) % 16 == 0 &&
+                reinterpret_cast<uintptr_t>(d_out) % 16 == 0, RAG_EINVAL, "rag_enc_attention_split: pointers must be 16-byte aligned");
+    RAG_REQUIRE(((int64_t)n_seq + 8) * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention_split: too many (sequence, head) pairs");
+    const int kpad = (max_seq_len + 31) & ~31;
+    const size_t lds = 2 * ((size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2);
+    RAG_REQUIRE(lds <= 160 * 1024, RAG_ELIMIT, "rag_enc_attention_split: sequences of %d tokens with head size %d need %zu bytes of LDS",
+                max_seq_len, head_dim, lds);
+    const float scale = 1.4426950408889634f / sqrtf((float)head_dim);
+    const unsigned grid = (unsigned)((int64_t)((n_seq + 7) / 8) * 8 * n_heads);
+    const int nt = first_only ? ATT_NT : 64 * std::min(4, (max_seq_len + 31) / 32);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (head_dim == 32) {
+        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_split_kernel<32>, 160 * 1024);
+        attention_split_kernel<32><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq, max_seq_len,
+                                                              n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
+    } else {
+        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_split_kernel<64>, 160 * 1024);
+        attention_split_kernel<64><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq, max_seq_len,
+                                                              n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
+    }
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 namespace {
 int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
                      int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_,
@@ -724,21 +974,11 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
         return RAG_OK;
     }
     if (head_dim == 32) {
-        static size_t granted = 64 * 1024;
-        if (lds > granted) {
-            RAG_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024));
-            granted = 160 * 1024;
-        }
+        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_kernel<32>, 160 * 1024);
         attention_kernel<32><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
                                                             n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     } else {
-        static size_t granted = 64 * 1024;
-        if (lds > granted) {
-            RAG_HIP_TRY(hipFuncSetAttribute((const void*)attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024));
-            granted = 160 * 1024;
-        }
+        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_kernel<64>, 160 * 1024);
         attention_kernel<64><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
                                                             n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
     }

@@ -10,6 +10,7 @@
 #include "merge.h"
 
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -670,6 +671,29 @@ uint32_t* rag_fault_word() {
         g_fault[dev] = w;
     }
     return g_fault[dev];
+}
+
+// dynamic-LDS grants, per (device, kernel)
+namespace {
+struct LdsGrant { const void* fn; size_t bytes; };
+std::mutex g_grant_mu;
+std::vector<LdsGrant> g_grants[MAX_DEVICES];
+}  // namespace
+
+int rag_grant_dyn_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return RAG_OK;                 // within the default limit
+    int dev = 0;
+    RAG_HIP_TRY(hipGetDevice(&dev));
+    RAG_REQUIRE(dev >= 0 && dev < MAX_DEVICES, RAG_ELIMIT, "device index %d beyond %d", dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_grant_mu);
+    LdsGrant* g = nullptr;
+    for (auto& e : g_grants[dev])
+        if (e.fn == kernel) g = &e;
+    if (g != nullptr && g->bytes >= bytes) return RAG_OK;
+    RAG_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (g != nullptr) g->bytes = bytes;
+    else g_grants[dev].push_back({kernel, bytes});
+    return RAG_OK;
 }
 
 extern "C" int rag_fault_flags(uint32_t* out_flags, int32_t clear) {

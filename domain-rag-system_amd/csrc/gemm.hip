@@ -229,12 +229,7 @@ __global__ __launch_bounds__(GM_NT, 1) void encoder_gemm_kernel(GemmParams p) {
 
 template <int EPI>
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)encoder_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GM_LDS_BYTES));
-        attr_set = true;
-    }
+    RAG_GRANT_LDS(encoder_gemm_kernel<EPI>, GM_LDS_BYTES);
     const dim3 grid((unsigned)ceil_div64(p.M, GM_BM), (unsigned)(p.N / GM_BN));
     hipLaunchKernelGGL(encoder_gemm_kernel<EPI>, grid, dim3(GM_NT), GM_LDS_BYTES, stream, p);
     RAG_HIP_TRY(hipGetLastError());

@@ -705,14 +705,10 @@ MlpProfile g_prof;
 int launch_mlp(const MlpParams& p, int mode, hipStream_t stream, const char* who) {
     RAG_REQUIRE(ceil_div64(p.M, ML_BM) < (1ll << 31), RAG_ELIMIT, "%s: too many rows", who);
     const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)p.I + 6 * ML_HID * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int max_lds = ML_OFF_B1 + 4 * ML_MAX_I + 6 * ML_HID * 2;
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)mlp_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-        attr_set = true;
-    }
+    const int max_lds = ML_OFF_B1 + 4 * ML_MAX_I + 6 * ML_HID * 2;
+    if (mode == 1) RAG_GRANT_LDS(mlp_fused_kernel<1>, max_lds);
+    else if (mode == 2) RAG_GRANT_LDS(mlp_fused_kernel<2>, max_lds);
+    else RAG_GRANT_LDS(mlp_fused_kernel<0>, max_lds);
     const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
     const bool timed = g_prof.on && g_prof.n < MlpProfile::RING;
     if (timed) RAG_HIP_TRY(hipEventRecord(g_prof.ev0[g_prof.n], stream));
@@ -849,12 +845,8 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear384: too many rows");
     const size_t lds_bytes = 2 * (size_t)ML_W_BYTES + 4 * (size_t)n;
     RAG_REQUIRE(lds_bytes <= 80 * 1024, RAG_ELIMIT, "rag_enc_linear384: output width %d too large", n);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        RAG_HIP_TRY(hipFuncSetAttribute((const void*)linear384_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
-    }
+    if (d_residual) RAG_GRANT_LDS(linear384_kernel<true>, 80 * 1024);
+    else RAG_GRANT_LDS(linear384_kernel<false>, 80 * 1024);
     LinearParams p = {};
     p.x = (const bf16*)d_x; p.w = (const bf16*)d_w; p.bias = (const bf16*)d_bias; p.y = (bf16*)d_y; p.M = m; p.N = n;
     p.residual = (const bf16*)d_residual; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.eps = eps;

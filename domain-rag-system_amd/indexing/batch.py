@@ -58,7 +58,8 @@ class BatchSearcher:
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
         self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
         self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
-        # unpadded cross-encoder batches when the model can run them (bfloat16 weights, native kernels)
+        # unpadded cross-encoder batches when the model can run them (native kernels; bfloat16 weights, or float32
+        # weights with split-precision GEMMs: the reference's precision, src/reranker/rerank.py:79-84)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_sort_by_length = True
         # sharded over RCCL: each rank embeds a slice of the queries and the slices are all-gathered
@@ -66,7 +67,9 @@ class BatchSearcher:
         self.split_embed = False
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
-            and next(cross_encoder.parameters()).dtype == torch.bfloat16)
+            and (next(cross_encoder.parameters()).dtype == torch.bfloat16
+                 or (next(cross_encoder.parameters()).dtype == torch.float32
+                     and getattr(cross_encoder.bert, 'split_gemm', False))))
         self.cls_id, self.sep_id, self.pad_id = special_ids
         self.dist = dist                                  # torch.distributed module when sharded
         self.world = dist.get_world_size() if dist is not None else 1
@@ -304,7 +307,7 @@ class BatchSearcher:
         safe = idx.clamp(min=0).long()
         out.update(rows=torch.where(idx >= 0, torch.gather(row, 1, safe), torch.full_like(safe, -1)),
                    scores=torch.gather(score, 1, safe), rerank_score=torch.gather(logits, 1, safe), count=rc,
-                   rerank_pos=idx)
+                   rerank_pos=idx, logits=logits)
         return out
 
     def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):

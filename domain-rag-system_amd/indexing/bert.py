@@ -104,6 +104,7 @@ class BertEncoder(nn.Module):
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
         self.fused_split_tails = True   # with split_gemm: one kernel for the work between two GEMMs
+        self.split_attention = True     # with split_gemm: attention as split-bf16 MFMA products (rag_enc_attention_split_dev)
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
@@ -169,7 +170,7 @@ class BertEncoder(nn.Module):
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
         if self.split_gemm and self.fused_split_tails and x.dtype == torch.float32:
-            return self._forward_packed_split(x, cu_seqlens, max_seq_len)
+            return self._forward_packed_split(x, cu_seqlens, max_seq_len, first_token_only)
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
         for li, l in enumerate(self.layers):
@@ -258,20 +259,36 @@ class BertEncoder(nn.Module):
             self._split_cache[id(module)] = w3
         return w3
 
-    def _forward_packed_split(self, x, cu_seqlens, max_seq_len):
+    def _forward_packed_split(self, x, cu_seqlens, max_seq_len, first_token_only=False):
         """The fp32 layers with every GEMM as a split-bf16 product (see _linear_split) and the work between
         two GEMMs in one kernel each: bias + residual + LayerNorm + split of the result, bias + GELU + split.
-        Same arithmetic in the same order as the separate kernels, so the same embeddings bit for bit."""
+        Same arithmetic in the same order as the separate kernels, so the same hidden states bit for bit.
+        Attention reads the fp32 q|k|v projection (its bias added on the way in) and writes the [hi|hi|lo]
+        operand of the output projection directly where the MFMA attention kernel covers the head size.
+        first_token_only: the last layer computes everything after its attention for the first row of every
+        sequence only ([n_seq, H] comes back); a classifier head reads nothing else."""
         import rag_hip
         mm = lambda a3, module: torch.mm(a3, self._split_weight(module).t(), out_dtype=torch.float32)
         xs = rag_hip.enc_split_bf16x3_dev(x)
         last = len(self.layers) - 1
+        head_dim = self.config.hidden_size // self.config.num_attention_heads
+        mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)
         for li, l in enumerate(self.layers):
-            qkv = mm(xs, l.qkv).add_(l.qkv.bias)
-            ctx = rag_hip.enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, l.heads)
-            x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(rag_hip.enc_split_bf16x3_dev(ctx), l.attn_out),
-                                                             l.attn_out.bias, x, l.attn_norm.weight, l.attn_norm.bias,
-                                                             l.attn_norm.eps)
+            cls_only = first_token_only and li == last
+            if mfma_attn:
+                # q|k|v bias inside the attention kernel; output already split for the next GEMM
+                ctx3 = rag_hip.enc_attention_split_dev(mm(xs, l.qkv), l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
+                                                       first_only=cls_only)
+            else:
+                qkv = mm(xs, l.qkv).add_(l.qkv.bias)
+                ctx = rag_hip.enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, l.heads)
+                if cls_only:
+                    ctx = ctx[cu_seqlens[:-1].long()]
+                ctx3 = rag_hip.enc_split_bf16x3_dev(ctx)
+            if cls_only:
+                x = x[cu_seqlens[:-1].long()]
+            x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(ctx3, l.attn_out), l.attn_out.bias, x,
+                                                             l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps)
             hs = rag_hip.enc_bias_act_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, True)
             x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(hs, l.ffn_out), l.ffn_out.bias, x, l.ffn_norm.weight,
                                                              l.ffn_norm.bias, l.ffn_norm.eps, want_split=li != last)
@@ -327,10 +344,11 @@ class CrossEncoderModel(nn.Module):
 
     def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
         """Logits of an unpadded batch (every sequence non-empty, first token [CLS])."""
-        if self.bert.word.weight.dtype == torch.bfloat16:
-            cls = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True)
+        b = self.bert
+        if b.word.weight.dtype == torch.bfloat16 or (b.split_gemm and b.fused_split_tails):
+            cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True)
         else:
-            cls = self.bert.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)[cu_seqlens[:-1].long()]
+            cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)[cu_seqlens[:-1].long()]
         logits = self.classifier(torch.tanh(self.pooler(cls)))
         return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
 

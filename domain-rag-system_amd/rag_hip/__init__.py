@@ -67,6 +67,7 @@ SIGNATURES = {
     'rag_enc_attention_dev': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
@@ -818,6 +819,31 @@ def enc_attention_packed_first_dev(qkv, cu_seqlens, max_seq_len, n_heads):
     check(lib().rag_enc_attention_packed_first_dev(_ptr(qkv, torch.bfloat16), _ptr(cu_seqlens, torch.int32), n_seq, t,
                                                    int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
                                                    _ptr(out), _stream()), 'rag_enc_attention_packed_first_dev')
+    return out
+
+
+def enc_attention_split_supported(head_dim, max_seq_len):
+    """Whether rag_enc_attention_split_dev covers this head size and sequence length (LDS holds a
+    head's keys and values twice: bf16 high and low parts)."""
+    if head_dim not in (32, 64) or max_seq_len > ENC_MAX_SEQ:
+        return False
+    kpad = (int(max_seq_len) + 31) // 32 * 32
+    return 2 * (kpad * (head_dim + 8) * 2 + head_dim * (kpad + 4) * 2) <= 160 * 1024
+
+
+def enc_attention_split_dev(qkv, bias, cu_seqlens, max_seq_len, n_heads, first_only=False):
+    """fp32-equivalent attention of a packed batch (rag_enc_attention_split_dev): qkv [T, 3*H] fp32 without
+    its bias, bias [3*H] fp32 or None -> bf16 [T or n_seq, 3*H] = [hi | hi | lo] of the attention output."""
+    import torch
+    t, h3 = qkv.shape
+    n_seq = cu_seqlens.shape[0] - 1
+    if bias is not None and tuple(bias.shape) != (h3,):
+        raise ValueError("bias must have one entry per projection column")
+    out = torch.empty((n_seq if first_only else t, h3), dtype=torch.bfloat16, device=qkv.device)
+    check(lib().rag_enc_attention_split_dev(_ptr(qkv, torch.float32), _ptr(bias, torch.float32),
+                                            _ptr(cu_seqlens, torch.int32), n_seq, t, int(max_seq_len), int(n_heads),
+                                            (h3 // 3) // int(n_heads), 1 if first_only else 0, _ptr(out), _stream()),
+          'rag_enc_attention_split_dev')
     return out
 
 

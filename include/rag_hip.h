@@ -304,6 +304,20 @@ int rag_enc_attention_packed_dev(const void* d_qkv, const int32_t* d_cu_seqlens,
 int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seq,
                                        int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
                                        int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* fp32-equivalent self-attention of a PACKED batch on the bf16 matrix cores, for running the
+ * cross-encoder forward at the reference's precision (CrossEncoder.predict computes in float32,
+ * reference src/reranker/rerank.py:79-84).  qkv [total_tokens][3][n_heads][head_dim] fp32 is the
+ * q|k|v projection WITHOUT its bias; bias [3 * n_heads * head_dim] fp32 (or NULL) is added while the
+ * operands are staged.  Every operand is split into bf16 high and low parts and every product taken
+ * as hi.hi + lo.hi + hi.lo with fp32 accumulation (relative error of a product below 2^-16; softmax
+ * in fp32).  out [rows][3 * H] bf16, H = n_heads * head_dim: row = [hi | hi | lo] of the attention
+ * output, the left operand of a split-precision GEMM (see rag_enc_split_bf16x3_dev); rows =
+ * total_tokens, or n_seq with first_only != 0 (only the first token of every sequence is a query:
+ * the last layer of a sequence classifier).  head_dim 32 or 64; max_seq_len bounds every sequence
+ * (head_dim 32: up to 512 tokens; 64: up to 288 by LDS size).                                  */
+int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
+                                int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                int32_t head_dim, int32_t first_only, void* d_out, void* stream);
 /* Sentence embedding of a packed fp32 batch: out[i] = mean of x over the tokens of
  * sequence i (the mean pooling over the attention mask of the sentence-transformers
  * pipeline behind reference src/indexing/embedder.py:65-71), L2-normalised when
