@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--rerank-top-n', type=int, default=50)
     ap.add_argument('--ce-dtype', default='fp32', choices=['fp32', 'bf16', 'fp32-torch'],
                     help="cross-encoder arithmetic: 'fp32' = float32 weights and activations, GEMMs and attention as "
-                         "split-bf16 matrix-core products with fp32 accumulation (the reference's precision, default); "
+                         "split-fp16 matrix-core products with fp32 accumulation (the reference's precision, default); "
                          "'bf16' = the bfloat16 kernels (faster, does not hold the fp32 order); 'fp32-torch' = plain PyTorch ops")
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary measurements (rerank_top_n=30, bf16 cross-encoder, batch sweep, host-buffer run) '
@@ -282,7 +282,7 @@ def main():
                                       native=not args.ce_torch_ops)
         elif kind == 'fp32':
             m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32, native=True,
-                                      split_gemm=True)
+                                      split_gemm=True, split_dtype=torch.float16)
         else:
             m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32)
         m.bert.fused_linear = bool(args.ce_fused_linear)
@@ -409,8 +409,8 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s / %s' % (
-            {'fp32': 'f32 cross-encoder forward with GEMMs and attention as 3 split-bf16 MFMA products, fp32 accumulation '
-                     '(logits within 2e-6 of the fp32 forward)',
+            {'fp32': 'f32 cross-encoder forward with GEMMs and attention as 3 split-fp16 MFMA products (x = hi + lo, 22 significant '
+                     'bits), fp32 accumulation: fp32 round-off class, see precision_check',
              'bf16': 'bf16 cross-encoder forward (does NOT hold the fp32 order: see precision_check)',
              'fp32-torch': 'f32 cross-encoder forward (PyTorch ops)'}[args.ce_dtype],
             'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else

@@ -21,6 +21,42 @@ typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16;
+
+// The 16-bit type a split-precision operand is held in: x = hi + lo with hi = H(x), lo = H(x - hi).
+// bf16 halves carry 16 significant bits between them (products good to 2^-16), fp16 halves 22 (products as
+// good as an fp32 product; fp16 subnormals are kept by the matrix cores, so small values lose nothing that
+// matters: absolute resolution 2^-25).  Both run at the same matrix-core rate.
+template <typename H> struct Half16;
+template <> struct Half16<__bf16> {
+    typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 x2 __attribute__((ext_vector_type(2)));
+    __device__ static f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Half16<_Float16> {
+    typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 x2 __attribute__((ext_vector_type(2)));
+    __device__ static f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// x = hi + lo with hi = H(x), lo = H(x - hi).  The hi that is stored has to be the hi that is subtracted: left to
+// itself the compiler folds a multiply or add that produced x into ONE of the two conversions (v_fma_mixlo_f16
+// rounds the exact product straight to fp16, the other path rounds to fp32 first), and next to a rounding tie
+// the two disagree by one fp16 ulp: hi + lo is then off by that ulp (seen as errors of 2^-10 in one element in
+// ten thousand).  Passing x through an opaque register makes it a finished fp32 value for both.
+template <typename H16>
+__device__ __forceinline__ float finished_f32(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+#define RAG_SPLIT_HI_LO(H16, x, hi, lo)                  \
+    do {                                                 \
+        const float _x = finished_f32<H16>(x);           \
+        (hi) = (H16)_x;                                  \
+        (lo) = (H16)(_x - (float)(hi));                  \
+    } while (0)
 
 constexpr int ATT_NT = 256;          // at most 4 waves; each takes 32-query blocks round-robin
 constexpr float NEG_BIG = -1e30f;    // finite stand-in for -inf (keeps max/exp free of NaN)
@@ -288,14 +324,17 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
 // GEMM output needs no bias pass); output is the attention result already split for the output
 // projection's GEMM: row = [hi | hi | lo], 3 * H bf16 (the left operand of [w_hi ; w_lo ; w_hi]).
 // Packed batches only (cu_seqlens).
-template <int D>
+template <int D, typename H16>
 __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float* __restrict__ qkv,
                                                                     const float* __restrict__ bias,
                                                                     const int32_t* __restrict__ cu, int64_t total_tokens,
                                                                     int n_seq, int S_max, int NH, float scale,
-                                                                    int first_only, bf16* __restrict__ out,
+                                                                    int first_only, H16* __restrict__ out,
                                                                     uint32_t* fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Half16<H16>::x8 hx8;
+    typedef typename Half16<H16>::x4 hx4;
+    typedef typename Half16<H16>::x2 hx2;
     constexpr int KROW = D + 8;
     constexpr int DT = D / 32;
     constexpr int KC = D / 16;
@@ -316,17 +355,17 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
     const int len = (int)n;
     const float* base = qkv + (size_t)first * tok + head * D;
     const float* bq = bias != nullptr ? bias + head * D : nullptr;
-    bf16* obase = (first_only ? out + (size_t)seq * tok : out + (size_t)first * tok) + head * D;
+    H16* obase = (first_only ? out + (size_t)seq * tok : out + (size_t)first * tok) + head * D;
     const int kpad = (len + 31) & ~31;
     const int VROW = kpad + 4;
-    bf16* Kh = reinterpret_cast<bf16*>(smem);
-    bf16* Kl = Kh + (size_t)kpad * KROW;
-    bf16* Vh = Kl + (size_t)kpad * KROW;
-    bf16* Vl = Vh + (size_t)D * VROW;
+    H16* Kh = reinterpret_cast<H16*>(smem);
+    H16* Kl = Kh + (size_t)kpad * KROW;
+    H16* Vh = Kl + (size_t)kpad * KROW;
+    H16* Vl = Vh + (size_t)D * VROW;
     const int n_query_rows = first_only ? min(1, len) : len;
 
     // eight consecutive fp32 values (+ bias) -> bf16 high and low parts
-    auto load8 = [&](const float* p, const float* b, bool live, bf16x8& hi, bf16x8& lo) {
+    auto load8 = [&](const float* p, const float* b, bool live, hx8& hi, hx8& lo) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (live) {
             const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
@@ -338,41 +377,39 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            hi[j] = (bf16)v[j];
-            lo[j] = (bf16)(v[j] - (float)hi[j]);
+            RAG_SPLIT_HI_LO(H16, v[j], hi[j], lo[j]);
         }
     };
-    auto load_q = [&](int q, bf16x8* qh, bf16x8* ql) {
+    auto load_q = [&](int q, hx8* qh, hx8* ql) {
 #pragma unroll
         for (int c = 0; c < KC; ++c)
             load8(base + (size_t)q * tok + 16 * c + 8 * h, bq != nullptr ? bq + 16 * c + 8 * h : nullptr,
                   q < n_query_rows, qh[c], ql[c]);
     };
-    bf16x8 qh[KC], ql[KC];
+    hx8 qh[KC], ql[KC];
     load_q(wave * 32 + r, qh, ql);
 
-    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
     for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += (int)blockDim.x) {
         const int key = (idx / (D / 8)) * 2, c8 = idx % (D / 8);
         const float* p = base + (size_t)key * tok + c8 * 8;
         const float* bk = bq != nullptr ? bq + H + c8 * 8 : nullptr;
         const float* bv = bq != nullptr ? bq + 2 * H + c8 * 8 : nullptr;
-        bf16x8 k0h, k0l, k1h, k1l, v0h, v0l, v1h, v1l;
+        hx8 k0h, k0l, k1h, k1l, v0h, v0l, v1h, v1l;
         load8(p + H, bk, key < len, k0h, k0l);
         load8(p + 2 * H, bv, key < len, v0h, v0l);
         load8(p + tok + H, bk, key + 1 < len, k1h, k1l);
         load8(p + tok + 2 * H, bv, key + 1 < len, v1h, v1l);
-        *reinterpret_cast<bf16x8*>(Kh + key * KROW + c8 * 8) = k0h;
-        *reinterpret_cast<bf16x8*>(Kl + key * KROW + c8 * 8) = k0l;
-        *reinterpret_cast<bf16x8*>(Kh + (key + 1) * KROW + c8 * 8) = k1h;
-        *reinterpret_cast<bf16x8*>(Kl + (key + 1) * KROW + c8 * 8) = k1l;
+        *reinterpret_cast<hx8*>(Kh + key * KROW + c8 * 8) = k0h;
+        *reinterpret_cast<hx8*>(Kl + key * KROW + c8 * 8) = k0l;
+        *reinterpret_cast<hx8*>(Kh + (key + 1) * KROW + c8 * 8) = k1h;
+        *reinterpret_cast<hx8*>(Kl + (key + 1) * KROW + c8 * 8) = k1l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            bf16x2 ph, pl;
+            hx2 ph, pl;
             ph[0] = v0h[j]; ph[1] = v1h[j];
             pl[0] = v0l[j]; pl[1] = v1l[j];
-            *reinterpret_cast<bf16x2*>(Vh + (c8 * 8 + j) * VROW + key) = ph;
-            *reinterpret_cast<bf16x2*>(Vl + (c8 * 8 + j) * VROW + key) = pl;
+            *reinterpret_cast<hx2*>(Vh + (c8 * 8 + j) * VROW + key) = ph;
+            *reinterpret_cast<hx2*>(Vl + (c8 * 8 + j) * VROW + key) = pl;
         }
     }
     __syncthreads();
@@ -393,11 +430,11 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Kh + (kb + r) * KROW + 16 * c + 8 * h);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(Kl + (kb + r) * KROW + 16 * c + 8 * h);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+                const hx8 ah = *reinterpret_cast<const hx8*>(Kh + (kb + r) * KROW + 16 * c + 8 * h);
+                const hx8 al = *reinterpret_cast<const hx8*>(Kl + (kb + r) * KROW + 16 * c + 8 * h);
+                s = Half16<H16>::mfma(al, qh[c], s);
+                s = Half16<H16>::mfma(ah, ql[c], s);
+                s = Half16<H16>::mfma(ah, qh[c], s);
             }
             float mx = NEG_BIG;
             if (kb + 32 > len) {
@@ -436,23 +473,22 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             m_run = m_new;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                bf16x8 pbh, pbl;
+                hx8 pbh, pbl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    pbh[j] = (bf16)s[8 * t + j];
-                    pbl[j] = (bf16)(s[8 * t + j] - (float)pbh[j]);
+                    RAG_SPLIT_HI_LO(H16, s[8 * t + j], pbh[j], pbl[j]);
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const size_t vo = (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
-                    const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(Vh + vo), h1 = *reinterpret_cast<const bf16x4*>(Vh + vo + 8);
-                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(Vl + vo), l1 = *reinterpret_cast<const bf16x4*>(Vl + vo + 8);
-                    bf16x8 avh, avl;
+                    const hx4 h0 = *reinterpret_cast<const hx4*>(Vh + vo), h1 = *reinterpret_cast<const hx4*>(Vh + vo + 8);
+                    const hx4 l0 = *reinterpret_cast<const hx4*>(Vl + vo), l1 = *reinterpret_cast<const hx4*>(Vl + vo + 8);
+                    hx8 avh, avl;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { avh[j] = h0[j]; avh[4 + j] = h1[j]; avl[j] = l0[j]; avl[4 + j] = l1[j]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avl, pbh, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, pbl, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(avh, pbh, o[dt], 0, 0, 0);
+                    o[dt] = Half16<H16>::mfma(avl, pbh, o[dt]);
+                    o[dt] = Half16<H16>::mfma(avh, pbl, o[dt]);
+                    o[dt] = Half16<H16>::mfma(avh, pbh, o[dt]);
                 }
             }
         }
@@ -479,16 +515,15 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             if (q < n_query_rows) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    bf16x8 hi, lo;
+                    hx8 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        hi[j] = (bf16)run[u][j];
-                        lo[j] = (bf16)(run[u][j] - (float)hi[j]);
+                        RAG_SPLIT_HI_LO(H16, run[u][j], hi[j], lo[j]);
                     }
-                    bf16* dst = obase + (size_t)q * tok + dt * 32 + 8 * h + 16 * u;
-                    *reinterpret_cast<bf16x8*>(dst) = hi;
-                    *reinterpret_cast<bf16x8*>(dst + H) = hi;
-                    *reinterpret_cast<bf16x8*>(dst + 2 * H) = lo;
+                    H16* dst = obase + (size_t)q * tok + dt * 32 + 8 * h + 16 * u;
+                    *reinterpret_cast<hx8*>(dst) = hi;
+                    *reinterpret_cast<hx8*>(dst + H) = hi;
+                    *reinterpret_cast<hx8*>(dst + 2 * H) = lo;
                 }
             }
         }
@@ -739,13 +774,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict_
 
 // LayerNorm((y + bias) + residual) in fp32, written as fp32 and, for the split-precision GEMM that reads it
 // next, as the bf16 row [hi | hi | lo] as well (out_split may be null).  One wave per row.
+template <typename H16>
 __global__ __launch_bounds__(256) void bias_add_layernorm_split_kernel(const float* __restrict__ y,
                                                                        const float* __restrict__ bias,
                                                                        const float* __restrict__ res,
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta, float eps,
                                                                        int64_t rows, int H, float* __restrict__ out,
-                                                                       bf16* __restrict__ out_split) {
+                                                                       H16* __restrict__ out_split) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -793,16 +829,15 @@ __global__ __launch_bounds__(256) void bias_add_layernorm_split_kernel(const flo
             for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
             Vec8<float>::store(out + row * H + ch * 8, o);
             if (out_split != nullptr) {
-                bf16x8 hi, lo;
+                typename Half16<H16>::x8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    hi[j] = (bf16)o[j];
-                    lo[j] = (bf16)(o[j] - (float)hi[j]);
+                    RAG_SPLIT_HI_LO(H16, o[j], hi[j], lo[j]);
                 }
-                bf16* p = out_split + row * 3 * H + ch * 8;
-                *reinterpret_cast<bf16x8*>(p) = hi;
-                *reinterpret_cast<bf16x8*>(p + H) = hi;
-                *reinterpret_cast<bf16x8*>(p + 2 * H) = lo;
+                H16* p = out_split + row * 3 * H + ch * 8;
+                *reinterpret_cast<typename Half16<H16>::x8*>(p) = hi;
+                *reinterpret_cast<typename Half16<H16>::x8*>(p + H) = hi;
+                *reinterpret_cast<typename Half16<H16>::x8*>(p + 2 * H) = lo;
             }
         }
     }
@@ -907,7 +942,10 @@ extern "C" int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32
 
 extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
                                            int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
-                                           int32_t head_dim, int32_t first_only, void* d_out, void* stream_) {
+                                           int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out,
+                                           void* stream_) {
+    RAG_REQUIRE(half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16, RAG_EINVAL,
+                "rag_enc_attention_split: the halves are bf16 or fp16");
     RAG_REQUIRE(n_seq >= 0 && max_seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention_split: bad sizes");
     RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention_split: head_dim must be 32 or 64 (got %d)",
                 head_dim);
@@ -925,15 +963,18 @@ extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bi
     const unsigned grid = (unsigned)((int64_t)((n_seq + 7) / 8) * 8 * n_heads);
     const int nt = first_only ? ATT_NT : 64 * std::min(4, (max_seq_len + 31) / 32);
     hipStream_t stream = (hipStream_t)stream_;
-    if (head_dim == 32) {
-        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_split_kernel<32>, 160 * 1024);
-        attention_split_kernel<32><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq, max_seq_len,
-                                                              n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
-    } else {
-        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_split_kernel<64>, 160 * 1024);
-        attention_split_kernel<64><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq, max_seq_len,
-                                                              n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
-    }
+#define RAG_ATT_SPLIT_LAUNCH(DD, HH)                                                                                  \
+    do {                                                                                                               \
+        if (lds > 64 * 1024) RAG_GRANT_LDS((attention_split_kernel<DD, HH>), 160 * 1024);                              \
+        attention_split_kernel<DD, HH><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq,    \
+                                                                  max_seq_len, n_heads, scale, first_only, (HH*)d_out, \
+                                                                  rag_fault_word());                                  \
+    } while (0)
+    if (head_dim == 32 && half_dtype == RAG_DTYPE_BF16) RAG_ATT_SPLIT_LAUNCH(32, bf16);
+    else if (head_dim == 32) RAG_ATT_SPLIT_LAUNCH(32, f16);
+    else if (half_dtype == RAG_DTYPE_BF16) RAG_ATT_SPLIT_LAUNCH(64, bf16);
+    else RAG_ATT_SPLIT_LAUNCH(64, f16);
+#undef RAG_ATT_SPLIT_LAUNCH
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -1044,24 +1085,24 @@ extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* 
 namespace {
 // x (fp32) = hi + lo + (what is left below 2^-17 relative), hi and lo in bf16; one row of the
 // output is [hi | hi | lo], the left operand of a GEMM against [w_hi ; w_lo ; w_hi].
+template <typename H16>
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, int64_t rows, int K,
-                                                           bf16* __restrict__ out) {
+                                                           H16* __restrict__ out) {
     const int64_t n8 = rows * (K / 8);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / (K / 8);
         const int c = (int)(i - row * (K / 8));
         float f[8];
         Vec8<float>::load(x + row * K + c * 8, f);
-        bf16x8 hi, lo;
+        typename Half16<H16>::x8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            hi[j] = (bf16)f[j];
-            lo[j] = (bf16)(f[j] - (float)hi[j]);
+            RAG_SPLIT_HI_LO(H16, f[j], hi[j], lo[j]);
         }
-        bf16* o = out + row * 3 * K + c * 8;
-        *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + K) = hi;
-        *reinterpret_cast<bf16x8*>(o + 2 * K) = lo;
+        H16* o = out + row * 3 * K + c * 8;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o) = hi;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o + K) = hi;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o + 2 * K) = lo;
     }
 }
 }  // namespace
@@ -1069,10 +1110,10 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 namespace {
 // The same split applied to act(y + bias): what stands between two split-precision GEMMs of the feed-forward
 // block (bias add, GELU and split were three passes over the widest activation of the layer).
-template <bool GELU>
+template <bool GELU, typename H16>
 __global__ __launch_bounds__(256) void bias_act_split_bf16x3_kernel(const float* __restrict__ y,
                                                                     const float* __restrict__ bias, int64_t rows, int K,
-                                                                    bf16* __restrict__ out) {
+                                                                    H16* __restrict__ out) {
     const int64_t n8 = rows * (K / 8);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / (K / 8);
@@ -1080,60 +1121,76 @@ __global__ __launch_bounds__(256) void bias_act_split_bf16x3_kernel(const float*
         float f[8], b[8];
         Vec8<float>::load(y + row * K + c * 8, f);
         Vec8<float>::load(bias + c * 8, b);
-        bf16x8 hi, lo;
+        typename Half16<H16>::x8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             f[j] += b[j];
             if (GELU) f[j] = 0.5f * f[j] * (1.0f + erff(f[j] * 0.70710678118654752f));
-            hi[j] = (bf16)f[j];
-            lo[j] = (bf16)(f[j] - (float)hi[j]);
+            RAG_SPLIT_HI_LO(H16, f[j], hi[j], lo[j]);
         }
-        bf16* o = out + row * 3 * K + c * 8;
-        *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + K) = hi;
-        *reinterpret_cast<bf16x8*>(o + 2 * K) = lo;
+        H16* o = out + row * 3 * K + c * 8;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o) = hi;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o + K) = hi;
+        *reinterpret_cast<typename Half16<H16>::x8*>(o + 2 * K) = lo;
     }
 }
 }  // namespace
 
 extern "C" int rag_enc_bias_act_split_bf16x3_dev(const float* d_y, const float* d_bias, int32_t gelu, int64_t rows,
-                                                 int32_t k, void* d_out, void* stream_) {
+                                                 int32_t k, int32_t half_dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16, RAG_EINVAL,
+                "rag_enc_bias_act_split_bf16x3: the halves are bf16 or fp16");
     RAG_REQUIRE(rows >= 0 && k >= 8 && k % 8 == 0, RAG_EINVAL,
                 "rag_enc_bias_act_split_bf16x3: k must be a positive multiple of 8");
     if (rows == 0) return RAG_OK;
     RAG_REQUIRE(d_y && d_bias && d_out, RAG_EINVAL, "rag_enc_bias_act_split_bf16x3: null pointer");
     const int64_t n8 = rows * (k / 8);
     const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
-    if (gelu)
-        bias_act_split_bf16x3_kernel<true><<<grid, 256, 0, (hipStream_t)stream_>>>(d_y, d_bias, rows, k, (bf16*)d_out);
-    else
-        bias_act_split_bf16x3_kernel<false><<<grid, 256, 0, (hipStream_t)stream_>>>(d_y, d_bias, rows, k, (bf16*)d_out);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (half_dtype == RAG_DTYPE_BF16) {
+        if (gelu) bias_act_split_bf16x3_kernel<true, bf16><<<grid, 256, 0, stream>>>(d_y, d_bias, rows, k, (bf16*)d_out);
+        else bias_act_split_bf16x3_kernel<false, bf16><<<grid, 256, 0, stream>>>(d_y, d_bias, rows, k, (bf16*)d_out);
+    } else {
+        if (gelu) bias_act_split_bf16x3_kernel<true, f16><<<grid, 256, 0, stream>>>(d_y, d_bias, rows, k, (f16*)d_out);
+        else bias_act_split_bf16x3_kernel<false, f16><<<grid, 256, 0, stream>>>(d_y, d_bias, rows, k, (f16*)d_out);
+    }
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
-extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream_) {
+extern "C" int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, int32_t half_dtype, void* d_out,
+                                        void* stream_) {
+    RAG_REQUIRE(half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16, RAG_EINVAL,
+                "rag_enc_split_bf16x3: the halves are bf16 or fp16");
     RAG_REQUIRE(rows >= 0 && k >= 8 && k % 8 == 0, RAG_EINVAL, "rag_enc_split_bf16x3: k must be a positive multiple of 8");
     if (rows == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_out, RAG_EINVAL, "rag_enc_split_bf16x3: null pointer");
     const int64_t n8 = rows * (k / 8);
     const unsigned grid = (unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1);
-    split_bf16x3_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (bf16*)d_out);
+    if (half_dtype == RAG_DTYPE_BF16) split_bf16x3_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (bf16*)d_out);
+    else split_bf16x3_kernel<f16><<<grid, 256, 0, (hipStream_t)stream_>>>(d_x, rows, k, (f16*)d_out);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
 extern "C" int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, const float* d_residual,
                                                    const float* d_gamma, const float* d_beta, float eps, int64_t rows,
-                                                   int32_t hidden, float* d_out, void* d_out_split, void* stream_) {
+                                                   int32_t hidden, int32_t half_dtype, float* d_out, void* d_out_split,
+                                                   void* stream_) {
+    RAG_REQUIRE(half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16, RAG_EINVAL,
+                "rag_enc_bias_add_layernorm_split: the halves are bf16 or fp16");
     RAG_REQUIRE(rows >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
                 "rag_enc_bias_add_layernorm_split: hidden must be a multiple of 8 up to %d", 8 * 64 * LN_MAX_CHUNKS);
     if (rows == 0) return RAG_OK;
     RAG_REQUIRE(d_y && d_bias && d_residual && d_gamma && d_beta && d_out, RAG_EINVAL,
                 "rag_enc_bias_add_layernorm_split: null pointer");
     RAG_REQUIRE((rows + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_bias_add_layernorm_split: too many rows");
-    bias_add_layernorm_split_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(
-        d_y, d_bias, d_residual, d_gamma, d_beta, eps, rows, hidden, d_out, (bf16*)d_out_split);
+    if (half_dtype == RAG_DTYPE_BF16)
+        bias_add_layernorm_split_kernel<bf16><<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(
+            d_y, d_bias, d_residual, d_gamma, d_beta, eps, rows, hidden, d_out, (bf16*)d_out_split);
+    else
+        bias_add_layernorm_split_kernel<f16><<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream_>>>(
+            d_y, d_bias, d_residual, d_gamma, d_beta, eps, rows, hidden, d_out, (f16*)d_out_split);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

@@ -104,7 +104,8 @@ class BertEncoder(nn.Module):
         self.split_gemm = False      # fp32 weights only: run the GEMMs as split-bf16 products (see _linear_split)
         self._split_cache = {}
         self.fused_split_tails = True   # with split_gemm: one kernel for the work between two GEMMs
-        self.split_attention = True     # with split_gemm: attention as split-bf16 MFMA products (rag_enc_attention_split_dev)
+        self.split_attention = True     # with split_gemm: attention as split-precision MFMA products (rag_enc_attention_split_dev)
+        self.split_dtype = torch.bfloat16   # 16-bit type of the split halves: bfloat16 (16 bits between them) or float16 (22)
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
@@ -255,7 +256,7 @@ class BertEncoder(nn.Module):
         import rag_hip
         w3 = self._split_cache.get(id(module))
         if w3 is None:
-            w3 = rag_hip.split_weight_bf16x3(module.weight.detach())
+            w3 = rag_hip.split_weight_bf16x3(module.weight.detach(), self.split_dtype)
             self._split_cache[id(module)] = w3
         return w3
 
@@ -269,7 +270,8 @@ class BertEncoder(nn.Module):
         sequence only ([n_seq, H] comes back); a classifier head reads nothing else."""
         import rag_hip
         mm = lambda a3, module: torch.mm(a3, self._split_weight(module).t(), out_dtype=torch.float32)
-        xs = rag_hip.enc_split_bf16x3_dev(x)
+        half = self.split_dtype
+        xs = rag_hip.enc_split_bf16x3_dev(x, half)
         last = len(self.layers) - 1
         head_dim = self.config.hidden_size // self.config.num_attention_heads
         mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)
@@ -278,20 +280,20 @@ class BertEncoder(nn.Module):
             if mfma_attn:
                 # q|k|v bias inside the attention kernel; output already split for the next GEMM
                 ctx3 = rag_hip.enc_attention_split_dev(mm(xs, l.qkv), l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
-                                                       first_only=cls_only)
+                                                       first_only=cls_only, half=half)
             else:
                 qkv = mm(xs, l.qkv).add_(l.qkv.bias)
                 ctx = rag_hip.enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, l.heads)
                 if cls_only:
                     ctx = ctx[cu_seqlens[:-1].long()]
-                ctx3 = rag_hip.enc_split_bf16x3_dev(ctx)
+                ctx3 = rag_hip.enc_split_bf16x3_dev(ctx, half)
             if cls_only:
                 x = x[cu_seqlens[:-1].long()]
             x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(ctx3, l.attn_out), l.attn_out.bias, x,
-                                                             l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps)
-            hs = rag_hip.enc_bias_act_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, True)
+                                                             l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps, half=half)
+            hs = rag_hip.enc_bias_act_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, True, half)
             x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(hs, l.ffn_out), l.ffn_out.bias, x, l.ffn_norm.weight,
-                                                             l.ffn_norm.bias, l.ffn_norm.eps, want_split=li != last)
+                                                             l.ffn_norm.bias, l.ffn_norm.eps, want_split=li != last, half=half)
         return x
 
     def _linear_split(self, module, x):
@@ -300,7 +302,7 @@ class BertEncoder(nn.Module):
         result differs from the fp32 GEMM by about 1e-5 relative, far inside the 1e-4 the
         embeddings have to hold on cosine scores, at a fraction of the fp32 matrix-core time."""
         import rag_hip
-        y = torch.mm(rag_hip.enc_split_bf16x3_dev(x), self._split_weight(module).t(), out_dtype=torch.float32)
+        y = torch.mm(rag_hip.enc_split_bf16x3_dev(x, self.split_dtype), self._split_weight(module).t(), out_dtype=torch.float32)
         return y.add_(module.bias)
 
 
@@ -450,13 +452,15 @@ def _resolve_dir(spec):
             f"({type(e).__name__}); pass a directory or a 'random:<arch>' spec") from e
 
 
-def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False):
+def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False, split_dtype=None):
     """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config).
     native=True runs attention and residual+LayerNorm through the librag_hip kernels (GPU,
     bfloat16 or float32, left-aligned attention masks; shapes they do not cover raise);
     native='auto' does so whenever the model sits on a GPU and has a head size the kernels
-    cover.  split_gemm=True (float32 weights, packed forward) runs the GEMMs as split-bf16
-    products with fp32 accumulation."""
+    cover.  split_gemm=True (float32 weights, packed forward) runs the GEMMs and attention as
+    split-precision products on the 16-bit matrix cores with fp32 accumulation; split_dtype =
+    torch.bfloat16 (default: results to ~1e-5 relative) or torch.float16 (to fp32 round-off;
+    activations and weights must stay below 65504)."""
     cls = BiEncoder if kind == 'bi' else CrossEncoderModel
     if spec.startswith('random:'):
         arch = spec.split(':', 1)[1]
@@ -490,6 +494,8 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
                   and cfg.hidden_size // cfg.num_attention_heads in (32, 64))
     model.bert.native = bool(native)
     model.bert.split_gemm = bool(split_gemm)
+    if split_dtype is not None:
+        model.bert.split_dtype = split_dtype
     return model, tok, cfg
 
 

@@ -16,7 +16,7 @@ METRIC_COSINE, METRIC_DOT, METRIC_EUCLID = 0, 1, 2
 MEM_HOST_COPY, MEM_DEVICE_COPY, MEM_DEVICE_BORROW = 0, 1, 2
 MAX_K = 1024
 MAX_FUSE_LIST = 512
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 ENC_MAX_SEQ = 512
 
 _METRICS = {'cosine': METRIC_COSINE, 'dot': METRIC_DOT, 'euclidean': METRIC_EUCLID, 'euclid': METRIC_EUCLID}
@@ -67,7 +67,7 @@ SIGNATURES = {
     'rag_enc_attention_dev': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
-    'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
@@ -81,9 +81,9 @@ SIGNATURES = {
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_norm_mlp_dev': (_i32, [_vp] * 10 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_gelu_dev': (_i32, [_vp, _i64, _i32, _vp]),
-    'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _vp, _vp]),
-    'rag_enc_bias_act_split_bf16x3_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
-    'rag_enc_bias_add_layernorm_split_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _vp, _vp, _vp]),
+    'rag_enc_split_bf16x3_dev': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    'rag_enc_bias_act_split_bf16x3_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    'rag_enc_bias_add_layernorm_split_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp, _vp]),
     'rag_enc_mean_pool_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
                                       _i32, _vp, _vp, _vp, _vp]),
@@ -758,30 +758,32 @@ def enc_mean_pool_dev(x, cu_seqlens, normalize=True):
     return out
 
 
-def enc_split_bf16x3_dev(x):
-    """fp32 [rows, K] -> bf16 [rows, 3K] = [hi | hi | lo] (rag_enc_split_bf16x3_dev)."""
+def enc_split_bf16x3_dev(x, half=None):
+    """fp32 [rows, K] -> `half` (bfloat16 unless given) [rows, 3K] = [hi | hi | lo] (rag_enc_split_bf16x3_dev)."""
     import torch
     rows, k = x.shape
-    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=x.device)
-    check(lib().rag_enc_split_bf16x3_dev(_ptr(x, torch.float32), rows, k, _ptr(out), _stream()),
+    code, hdt = _half_code(half)
+    out = torch.empty((rows, 3 * k), dtype=hdt, device=x.device)
+    check(lib().rag_enc_split_bf16x3_dev(_ptr(x, torch.float32), rows, k, code, _ptr(out), _stream()),
           'rag_enc_split_bf16x3_dev')
     return out
 
 
-def enc_bias_act_split_dev(y, bias, gelu):
+def enc_bias_act_split_dev(y, bias, gelu, half=None):
     """fp32 y [rows, K], bias [K] -> bf16 [rows, 3K] = split of act(y + bias), act = exact GELU or identity
     (rag_enc_bias_act_split_bf16x3_dev)."""
     import torch
     rows, k = y.shape
     if tuple(bias.shape) != (k,):
         raise ValueError("bias must have one entry per column")
-    out = torch.empty((rows, 3 * k), dtype=torch.bfloat16, device=y.device)
+    code, hdt = _half_code(half)
+    out = torch.empty((rows, 3 * k), dtype=hdt, device=y.device)
     check(lib().rag_enc_bias_act_split_bf16x3_dev(_ptr(y, torch.float32), _ptr(bias, torch.float32), 1 if gelu else 0,
-                                                  rows, k, _ptr(out), _stream()), 'rag_enc_bias_act_split_bf16x3_dev')
+                                                  rows, k, code, _ptr(out), _stream()), 'rag_enc_bias_act_split_bf16x3_dev')
     return out
 
 
-def enc_bias_add_layernorm_split_dev(y, bias, residual, gamma, beta, eps, want_split=True):
+def enc_bias_add_layernorm_split_dev(y, bias, residual, gamma, beta, eps, want_split=True, half=None):
     """fp32 LayerNorm((y + bias) + residual) -> (out fp32 [rows, H], its bf16 split [rows, 3H] or None)
     (rag_enc_bias_add_layernorm_split_dev)."""
     import torch
@@ -791,20 +793,23 @@ def enc_bias_add_layernorm_split_dev(y, bias, residual, gamma, beta, eps, want_s
     if tuple(bias.shape) != (h,) or tuple(gamma.shape) != (h,) or tuple(beta.shape) != (h,):
         raise ValueError("bias, gamma and beta must have one entry per hidden unit")
     out = torch.empty_like(y)
-    split = torch.empty((rows, 3 * h), dtype=torch.bfloat16, device=y.device) if want_split else None
+    code, hdt = _half_code(half)
+    split = torch.empty((rows, 3 * h), dtype=hdt, device=y.device) if want_split else None
     check(lib().rag_enc_bias_add_layernorm_split_dev(_ptr(y, torch.float32), _ptr(bias, torch.float32),
                                                      _ptr(residual, torch.float32), _ptr(gamma, torch.float32),
-                                                     _ptr(beta, torch.float32), float(eps), rows, h, _ptr(out),
+                                                     _ptr(beta, torch.float32), float(eps), rows, h, code, _ptr(out),
                                                      _ptr(split) if split is not None else None, _stream()),
           'rag_enc_bias_add_layernorm_split_dev')
     return out, split
 
 
-def split_weight_bf16x3(w):
-    """fp32 weight [N, K] -> bf16 [N, 3K] = [w_hi | w_lo | w_hi], the partner of enc_split_bf16x3_dev."""
+def split_weight_bf16x3(w, half=None):
+    """fp32 weight [N, K] -> `half` (bfloat16 unless given) [N, 3K] = [w_hi | w_lo | w_hi], the partner of
+    enc_split_bf16x3_dev."""
     import torch
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    _, hdt = _half_code(half)
+    hi = w.to(hdt)
+    lo = (w - hi.float()).to(hdt)
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
@@ -831,18 +836,29 @@ def enc_attention_split_supported(head_dim, max_seq_len):
     return 2 * (kpad * (head_dim + 8) * 2 + head_dim * (kpad + 4) * 2) <= 160 * 1024
 
 
-def enc_attention_split_dev(qkv, bias, cu_seqlens, max_seq_len, n_heads, first_only=False):
-    """fp32-equivalent attention of a packed batch (rag_enc_attention_split_dev): qkv [T, 3*H] fp32 without
-    its bias, bias [3*H] fp32 or None -> bf16 [T or n_seq, 3*H] = [hi | hi | lo] of the attention output."""
+def _half_code(half):
+    """RAG_DTYPE_* code of the 16-bit type split-precision operands are held in (None = bfloat16)."""
     import torch
+    if half is None or half == torch.bfloat16:
+        return DTYPE_BF16, torch.bfloat16
+    if half == torch.float16:
+        return DTYPE_F16, torch.float16
+    raise ValueError(f"split-precision halves are bfloat16 or float16, not {half}")
+
+
+def enc_attention_split_dev(qkv, bias, cu_seqlens, max_seq_len, n_heads, first_only=False, half=None):
+    """fp32-equivalent attention of a packed batch (rag_enc_attention_split_dev): qkv [T, 3*H] fp32 without
+    its bias, bias [3*H] fp32 or None -> `half` [T or n_seq, 3*H] = [hi | hi | lo] of the attention output."""
+    import torch
+    code, hdt = _half_code(half)
     t, h3 = qkv.shape
     n_seq = cu_seqlens.shape[0] - 1
     if bias is not None and tuple(bias.shape) != (h3,):
         raise ValueError("bias must have one entry per projection column")
-    out = torch.empty((n_seq if first_only else t, h3), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((n_seq if first_only else t, h3), dtype=hdt, device=qkv.device)
     check(lib().rag_enc_attention_split_dev(_ptr(qkv, torch.float32), _ptr(bias, torch.float32),
                                             _ptr(cu_seqlens, torch.int32), n_seq, t, int(max_seq_len), int(n_heads),
-                                            (h3 // 3) // int(n_heads), 1 if first_only else 0, _ptr(out), _stream()),
+                                            (h3 // 3) // int(n_heads), 1 if first_only else 0, code, _ptr(out), _stream()),
           'rag_enc_attention_split_dev')
     return out
 

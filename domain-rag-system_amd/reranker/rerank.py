@@ -90,7 +90,12 @@ class CrossEncoderReranker(BaseReranker):
                  max_length: int = 512):
         super().__init__(top_n=top_n, name="cross-encoder")
         self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
-        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'cross', self.device, dtype=dtype, native='auto')
+        # float32 on the GPU: GEMMs and attention as split-fp16 matrix-core products (fp32 round-off class), the
+        # reference's precision (CrossEncoder.predict, reference src/reranker/rerank.py:79-84) at matrix-core speed
+        on_gpu = torch.device(self.device).type == 'cuda'
+        self.model, self.tokenizer, cfg = bert.load_model(model_name, 'cross', self.device, dtype=dtype, native='auto',
+                                                          split_gemm=on_gpu and dtype == torch.float32,
+                                                          split_dtype=torch.float16)
         self.batch_size = batch_size
         self.max_length = min(max_length, cfg.max_position_embeddings)
 

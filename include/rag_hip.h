@@ -280,6 +280,7 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
  * their GEMMs in hipBLASLt; these entry points are what runs between the GEMMs.        */
 #define RAG_DTYPE_F32   0
 #define RAG_DTYPE_BF16  1
+#define RAG_DTYPE_F16   2   /* only as the 16-bit half type of split-precision operands  */
 #define RAG_ENC_MAX_SEQ 512   /* longest sequence of rag_enc_attention_dev              */
 
 /* Self-attention of n_seq padded sequences: qkv is the packed projection output
@@ -309,15 +310,16 @@ int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_se
  * reference src/reranker/rerank.py:79-84).  qkv [total_tokens][3][n_heads][head_dim] fp32 is the
  * q|k|v projection WITHOUT its bias; bias [3 * n_heads * head_dim] fp32 (or NULL) is added while the
  * operands are staged.  Every operand is split into bf16 high and low parts and every product taken
- * as hi.hi + lo.hi + hi.lo with fp32 accumulation (relative error of a product below 2^-16; softmax
- * in fp32).  out [rows][3 * H] bf16, H = n_heads * head_dim: row = [hi | hi | lo] of the attention
+ * as hi.hi + lo.hi + hi.lo with fp32 accumulation (softmax in fp32).  half_dtype = RAG_DTYPE_BF16 or
+ * RAG_DTYPE_F16 is the type of the halves, of the internal ones and of the output's (see
+ * rag_enc_split_bf16x3_dev).  out [rows][3 * H], H = n_heads * head_dim: row = [hi | hi | lo] of the attention
  * output, the left operand of a split-precision GEMM (see rag_enc_split_bf16x3_dev); rows =
  * total_tokens, or n_seq with first_only != 0 (only the first token of every sequence is a query:
  * the last layer of a sequence classifier).  head_dim 32 or 64; max_seq_len bounds every sequence
  * (head_dim 32: up to 512 tokens; 64: up to 288 by LDS size).                                  */
 int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
                                 int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
-                                int32_t head_dim, int32_t first_only, void* d_out, void* stream);
+                                int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out, void* stream);
 /* Sentence embedding of a packed fp32 batch: out[i] = mean of x over the tokens of
  * sequence i (the mean pooling over the attention mask of the sentence-transformers
  * pipeline behind reference src/indexing/embedder.py:65-71), L2-normalised when
@@ -392,21 +394,27 @@ int rag_enc_gelu_dev(void* d_x, int64_t n, int32_t dtype, void* stream);
  * row x[r][0..k) becomes the bf16 row [hi | hi | lo] of 3k elements (hi = bf16(x),
  * lo = bf16(x - hi)).  Multiplied (fp32 accumulation) by weights laid out as
  * [w_hi ; w_lo ; w_hi] along k it yields x_hi w_hi + x_hi w_lo + x_lo w_hi, i.e. the fp32
- * product to about 2^-16 relative per term (the dropped x_lo w_lo term).               */
-int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, void* d_out, void* stream);
+ * product to about 2^-16 relative per term (the dropped x_lo w_lo term).
+ * half_dtype selects the 16-bit type of the halves (here and in the entry points below that write such
+ * rows): RAG_DTYPE_BF16 as described, or RAG_DTYPE_F16: 11 significant bits per half instead of 8, so
+ * the three products give the fp32 product to fp32 round-off (measured on a 4096 x 384 x 1536 GEMM of unit
+ * normal inputs and 0.03-normal weights: mean error 3.0e-7 against 1.5e-7 for an fp32 GEMM and 2.1e-6 for
+ * bf16 halves); fp16 subnormals are honoured by the matrix cores, values must stay below 65504.       */
+int rag_enc_split_bf16x3_dev(const float* d_x, int64_t rows, int32_t k, int32_t half_dtype, void* d_out, void* stream);
 /* The same split of act(y + bias) (bias [k] fp32; gelu != 0: exact erf GELU, else identity): what
  * stands between the two split-precision GEMMs of BERT's feed-forward block
  * (transformers BertIntermediate, reached through SentenceTransformer.encode,
  * reference src/indexing/embedder.py:65-71).                                              */
 int rag_enc_bias_act_split_bf16x3_dev(const float* d_y, const float* d_bias, int32_t gelu, int64_t rows,
-                                      int32_t k, void* d_out, void* stream);
+                                      int32_t k, int32_t half_dtype, void* d_out, void* stream);
 /* out[r] = LayerNorm((y[r] + bias) + residual[r]) * gamma + beta in fp32 (BertSelfOutput /
  * BertOutput behind reference src/indexing/embedder.py:65-71), and, when d_out_split is not
  * NULL, the bf16 row [hi | hi | lo] of out[r] (3 * hidden elements) for the split-precision
  * GEMM that reads it next.  hidden a multiple of 8 up to 2048; out may alias y or residual. */
 int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, const float* d_residual,
                                          const float* d_gamma, const float* d_beta, float eps, int64_t rows,
-                                         int32_t hidden, float* d_out, void* d_out_split, void* stream);
+                                         int32_t hidden, int32_t half_dtype, float* d_out, void* d_out_split,
+                                         void* stream);
 /* BERT's input embedding: out[t] = LayerNorm(word[ids[t]] + position[pos[t]] +
  * type_emb[types[t]]) (types NULL = all 0), tables [vocab|max_pos|n_types][hidden];
  * ids outside a table are clamped and flagged (RAG_FAULT_TOKEN).                        */

@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--seed', type=int, default=5)
     ap.add_argument('--init', default=None, help='weight initialisation of the random model (bert.INITS)')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--ref64', action='store_true', help='also compare every form with a float64 forward')
+    ap.add_argument('--halves', default='fp16', choices=['fp16', 'bf16'], help='16-bit type of the split operands')
     ap.add_argument('--only', default=None, choices=['bf16', 'split'], help='run one path only (for profiling)')
     args = ap.parse_args()
     import rag_hip
@@ -56,7 +58,8 @@ def main():
     rag_hip.init(0)
     kw = {} if args.init is None else {'init': args.init}
     ce_bf, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.bfloat16, native=True, **kw)
-    ce_sp, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float32, native=True, split_gemm=True, **kw)
+    ce_sp, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                  split_dtype=torch.bfloat16 if args.halves == 'bf16' else torch.float16, **kw)
     ce_32, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float32, **kw)
 
     ids, types, pos, cu = make_pairs(args.queries, args.top_n, args.seed)
@@ -94,6 +97,28 @@ def main():
             return torch.cat(outs)
         lg_32, ms_32 = timed(torch32, reps=1)
     rag_hip.check_faults()
+    if args.ref64:
+        # float64 forward as the yardstick: errors of the float32 PyTorch forward and of both split forms
+        ce_64, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float64, **kw)
+        ce_sb, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                      split_dtype=torch.bfloat16, **kw)
+        ce_sh, _, _ = bert.load_model('random:' + args.arch, 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                      split_dtype=torch.float16, **kw)
+        with torch.no_grad():
+            outs = []
+            for s0 in range(0, n_pairs, 256):
+                it, mt = bert.pad_batch([x.tolist() for x in ids[s0:s0 + 256]], 0, dev)
+                tt, _ = bert.pad_batch([x.tolist() for x in types[s0:s0 + 256]], 0, dev)
+                h = ce_64.bert(it, tt, mt)
+                outs.append(ce_64.classifier(torch.tanh(ce_64.pooler(h[:, 0]))).squeeze(-1))
+            r64 = torch.cat(outs)
+            sb = ce_sb.forward_packed(p_ids, p_types, p_pos, cu_d, longest).double()
+            sh = ce_sh.forward_packed(p_ids, p_types, p_pos, cu_d, longest).double()
+        def stat(x):
+            e = (x - r64).abs()
+            return {'max': float(e.max()), 'p999': float(torch.quantile(e, 0.999)), 'mean': float(e.mean())}
+        print(json.dumps({'vs_float64': {'torch_fp32': stat(lg_32.double()), 'split_bf16_halves': stat(sb),
+                                         'split_fp16_halves': stat(sh)}}, indent=1))
     a = lg_bf.double().cpu().numpy().reshape(args.queries, args.top_n)
     s = lg_sp.double().cpu().numpy().reshape(args.queries, args.top_n)
     r = lg_32.double().cpu().numpy().reshape(args.queries, args.top_n)

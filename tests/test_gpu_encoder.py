@@ -282,11 +282,103 @@ def test_split_tails_equal_the_separate_kernels_bit_for_bit():
     mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
     packed = model.bert.pack(ids, mask)
     with torch.no_grad():
-        assert model.bert.fused_split_tails
+        assert model.bert.fused_split_tails and model.bert.split_attention
+        with_mfma_attention = model.forward_packed(*packed, normalize=True)
+        model.bert.split_attention = False          # plain fp32 attention in both forms
         fused = model.forward_packed(*packed, normalize=True)
         model.bert.fused_split_tails = False
         separate = model.forward_packed(*packed, normalize=True)
     assert torch.equal(fused, separate)
+    # attention as split-bf16 matrix-core products: the same embeddings to fp32 round-off
+    assert float((with_mfma_attention - fused).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('half', ['fp16', 'bf16'])
+@pytest.mark.parametrize('heads,head_dim,max_len,n_seq,mag', [
+    (12, 32, 157, 61, 0.3), (12, 32, 157, 61, 1.5), (12, 64, 40, 33, 0.3), (4, 32, 300, 9, 0.5), (2, 64, 288, 5, 0.3),
+    (12, 32, 1, 3, 1.0)])
+def test_split_attention_matches_fp64_and_first_only(heads, head_dim, max_len, n_seq, mag, half):
+    """rag_enc_attention_split_dev: fp32 q|k|v (+ bias) -> [hi | hi | lo] of the attention output, against a
+    float64 softmax(QK^T/sqrt(d))V.  With fp16 halves (22 significant bits) the result is as good as plain fp32
+    arithmetic; with bf16 halves (16 bits) a product is good to 2^-16 of sum |q_i||k_i|, so the error grows with
+    the operands' magnitude (`mag` 0.3 is what LayerNorm-ed inputs times 0.02-0.05 weights give; 1.5 means
+    attention logits of +-10)."""
+    import rag_hip
+    dev = torch.device('cuda:0')
+    hdt = torch.float16 if half == 'fp16' else torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(100 + heads + max_len)
+    hid = heads * head_dim
+    lens = torch.randint(1, max_len + 1, (n_seq,), generator=g, device=dev, dtype=torch.int32)
+    lens[0] = max_len
+    cu = torch.zeros((n_seq + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    t = int(cu[-1])
+    qkv = torch.randn((t, 3 * hid), generator=g, device=dev) * mag
+    bias = torch.randn((3 * hid,), generator=g, device=dev) * (mag / 3)
+    assert rag_hip.enc_attention_split_supported(head_dim, max_len)
+    out3 = rag_hip.enc_attention_split_dev(qkv, bias, cu, max_len, heads, half=hdt)
+    first3 = rag_hip.enc_attention_split_dev(qkv, bias, cu, max_len, heads, first_only=True, half=hdt)
+    nobias3 = rag_hip.enc_attention_split_dev(qkv + bias, None, cu, max_len, heads, half=hdt)
+    torch.cuda.synchronize()
+    assert out3.dtype == hdt and tuple(out3.shape) == (t, 3 * hid) and tuple(first3.shape) == (n_seq, 3 * hid)
+    assert torch.equal(out3[:, :hid], out3[:, hid:2 * hid])
+    assert torch.equal(first3, out3[cu[:-1].long()])
+    assert torch.equal(nobias3, out3)
+    got = out3[:, :hid].double() + out3[:, 2 * hid:].double()
+    full = (qkv + bias).double()
+    cu_h = cu.cpu().tolist()
+    worst = scale = 0.0
+    for i in range(n_seq):
+        x = full[cu_h[i]:cu_h[i + 1]].view(-1, 3, heads, head_dim)
+        q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)
+        p = torch.softmax(q @ k.transpose(1, 2) / head_dim ** 0.5, dim=-1)
+        ref = (p @ v).transpose(0, 1).reshape(-1, hid)
+        worst = max(worst, float((got[cu_h[i]:cu_h[i + 1]] - ref).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+    # fp16 halves: a few fp32 ulps of the largest value (exp2 and fp32 accumulation included)
+    tol = 4e-6 * max(scale, 1.0) * (1 + mag * mag * 4) if half == 'fp16' else 2e-4 * max(mag, 0.3) ** 2 / 0.09 * 0.1
+    assert worst < tol, (worst, tol)
+    # hi is the 16-bit rounding of the result, lo the rounding of what is left
+    assert float((out3[:, :hid].float() - got.float()).abs().max()) <= 2 ** -8 * float(got.abs().max())
+
+
+def test_cross_encoder_fp32_split_path_holds_the_fp32_order():
+    """The float32 cross-encoder with split-bf16 GEMMs and attention (the default of the batched path) against
+    the plain PyTorch float32 forward: logits within 5e-6, and the same top-5 of every 50-pair pool wherever the
+    float32 logits that decide it are 2e-5 apart (reference: CrossEncoder.predict, src/reranker/rerank.py:79-84)."""
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    fast, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                   split_dtype=torch.float16)
+    plain, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32)
+    g = torch.Generator(device=dev).manual_seed(77)
+    n_q, pool = 24, 50
+    ids_l, typ_l = [], []
+    for _ in range(n_q):
+        q = torch.randint(1000, cfg.vocab_size, (int(torch.randint(8, 25, (1,), generator=g, device=dev)),), generator=g, device=dev)
+        for _ in range(pool):
+            c = torch.randint(1000, cfg.vocab_size, (int(torch.randint(4, 130, (1,), generator=g, device=dev)),), generator=g, device=dev)
+            ids_l.append([101] + q.tolist() + [102] + c.tolist() + [102])
+            typ_l.append([0] * (len(q) + 2) + [1] * (len(c) + 1))
+    cu = torch.tensor([0] + [len(x) for x in ids_l], device=dev).cumsum(0).to(torch.int32)
+    flat = lambda l: torch.tensor([v for x in l for v in x], dtype=torch.int32, device=dev)
+    pos = torch.cat([torch.arange(len(x), dtype=torch.int32, device=dev) for x in ids_l])
+    with torch.no_grad():
+        got = fast.forward_packed(flat(ids_l), flat(typ_l), pos, cu, max(len(x) for x in ids_l))
+        want = []
+        for s0 in range(0, len(ids_l), 200):
+            it, mt = bert.pad_batch(ids_l[s0:s0 + 200], 0, dev)
+            tt, _ = bert.pad_batch(typ_l[s0:s0 + 200], 0, dev)
+            want.append(plain(it, tt, mt))
+        want = torch.cat(want)
+    assert float((got - want).abs().max()) < 5e-6
+    got, want = got.view(n_q, pool).double(), want.view(n_q, pool).double()
+    srt = torch.sort(want, dim=1, descending=True).values
+    decided = (srt[:, :5] - srt[:, 1:6]).min(dim=1).values >= 2e-5
+    same = (torch.argsort(got, dim=1, descending=True, stable=True)[:, :5]
+            == torch.argsort(want, dim=1, descending=True, stable=True)[:, :5]).all(dim=1)
+    assert int(decided.sum()) >= n_q // 2           # the check is not vacuous
+    assert bool(same[decided].all())
 
 
 def test_first_token_attention_equals_row_zero_of_the_full_kernel():
