@@ -22,6 +22,8 @@
 // merged K-th score seeds the shared threshold, then on the rest, which then emit about 16 K
 // candidates per query in all instead of dozens per tile.
 #include "common.h"
+
+#include <mutex>
 #include "merge.h"
 
 #include <stdlib.h>
@@ -293,8 +295,13 @@ extern "C" int64_t rag_bm25_docs(rag_bm25_t h) { return h ? h->n_docs : -1; }
 
 namespace {
 
+size_t bm25_toff_bytes(rag_bm25_t h, int n_terms_total) {
+    return ((size_t)n_terms_total * ((size_t)ceil_div64(h->n_docs, BM_TILE) + 1) + 1) * sizeof(uint32_t);
+}
+
+// `toff` = device buffer of bm25_toff_bytes() bytes, or NULL: then the handle's own buffer is grown as needed
 int bm25_prepare(rag_bm25_t h, Bm25Params& p, const int32_t* d_qterms, const int32_t* d_qoff, int n_queries,
-                 int n_terms_total, hipStream_t stream) {
+                 int n_terms_total, hipStream_t stream, uint32_t* toff = nullptr) {
     p.indptr = h->indptr;
     p.rows = h->rows;
     p.impact = h->impact;
@@ -307,9 +314,12 @@ int bm25_prepare(rag_bm25_t h, Bm25Params& p, const int32_t* d_qterms, const int
     p.n_queries = n_queries;
     p.n_terms_total = n_terms_total;
     p.n_tiles = (int)ceil_div64(h->n_docs, BM_TILE);
-    int rc = h->toff.ensure(((size_t)n_terms_total * (p.n_tiles + 1) + 1) * sizeof(uint32_t));
-    if (rc) return rc;
-    p.toff = (uint32_t*)h->toff.p;
+    if (toff == nullptr) {
+        int rc = h->toff.ensure(bm25_toff_bytes(h, n_terms_total));
+        if (rc) return rc;
+        toff = (uint32_t*)h->toff.p;
+    }
+    p.toff = toff;
     if (n_terms_total > 0) {
         const int64_t n = (int64_t)n_terms_total * (p.n_tiles + 1);
         bm25_offsets_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(p);
@@ -320,37 +330,59 @@ int bm25_prepare(rag_bm25_t h, Bm25Params& p, const int32_t* d_qterms, const int
 
 }  // namespace
 
-extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
-                                   int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row,
-                                   int32_t* d_out_count, void* stream_) {
+namespace {
+
+// Device work buffers of one search: per-(term, tile) posting offsets, per-query thresholds, the
+// per-query candidate lists and their counters.
+struct Bm25Work {
+    uint32_t* toff;
+    unsigned long long* tau;
+    uint64_t* cand_key;
+    uint32_t* cand_row;
+    int32_t* cand_count;
+};
+struct Bm25WorkBytes {
+    size_t toff, tau, cand_key, cand_row, cand_count;
+};
+Bm25WorkBytes bm25_work_bytes(rag_bm25_t h, int n_queries, int n_terms_total, int k) {
+    const size_t slots = (size_t)n_queries * (size_t)ceil_div64(h->n_docs, BM_TILE);
+    return {bm25_toff_bytes(h, n_terms_total), (size_t)n_queries * sizeof(unsigned long long), slots * k * sizeof(uint64_t),
+            slots * k * sizeof(uint32_t), (size_t)n_queries * sizeof(int32_t)};
+}
+
+int bm25_check_search_args(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
+                           int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row,
+                           int32_t* d_out_count) {
     RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_bm25_search: null handle");
     RAG_REQUIRE(n_queries >= 0 && n_terms_total >= 0 && k >= 1 && k <= RAG_MAX_K, RAG_ELIMIT,
                 "rag_bm25_search: need n_queries >= 0 and 1 <= k <= %d (got %d, %d)", RAG_MAX_K, n_queries, k);
-    if (n_queries == 0) return RAG_OK;
-    RAG_REQUIRE(d_qoff && d_out_score && d_out_row && d_out_count && (d_qterms || n_terms_total == 0), RAG_EINVAL,
-                "rag_bm25_search: null pointer");
-    hipStream_t stream = (hipStream_t)stream_;
-    if (h->n_docs == 0) {
-        RAG_HIP_TRY(hipMemsetAsync(d_out_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
-        RAG_HIP_TRY(hipMemsetAsync(d_out_row, 0xff, (size_t)n_queries * k * sizeof(int64_t), stream));
-        RAG_HIP_TRY(hipMemsetAsync(d_out_score, 0, (size_t)n_queries * k * sizeof(double), stream));
-        return RAG_OK;
-    }
+    RAG_REQUIRE(n_queries == 0 || (d_qoff && d_out_score && d_out_row && d_out_count && (d_qterms || n_terms_total == 0)),
+                RAG_EINVAL, "rag_bm25_search: null pointer");
+    return RAG_OK;
+}
+
+int bm25_empty_result(int32_t n_queries, int32_t k, double* d_out_score, int64_t* d_out_row, int32_t* d_out_count,
+                      hipStream_t stream) {
+    RAG_HIP_TRY(hipMemsetAsync(d_out_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
+    RAG_HIP_TRY(hipMemsetAsync(d_out_row, 0xff, (size_t)n_queries * k * sizeof(int64_t), stream));
+    RAG_HIP_TRY(hipMemsetAsync(d_out_score, 0, (size_t)n_queries * k * sizeof(double), stream));
+    return RAG_OK;
+}
+
+// The search proper on given work buffers (sized by bm25_work_bytes); allocates nothing.
+int bm25_search_on(rag_bm25_t h, const Bm25Work& w, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
+                   int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row, int32_t* d_out_count,
+                   hipStream_t stream) {
     Bm25Params p;
     memset(&p, 0, sizeof(p));
-    int rc = bm25_prepare(h, p, d_qterms, d_qoff, n_queries, n_terms_total, stream);
+    int rc = bm25_prepare(h, p, d_qterms, d_qoff, n_queries, n_terms_total, stream, w.toff);
     if (rc) return rc;
     p.k = k;
     p.share_tau = getenv("RAG_BM25_NO_TAU") ? 0 : 1;
-    const size_t slots = (size_t)n_queries * p.n_tiles;
-    if ((rc = h->tau.ensure((size_t)n_queries * sizeof(unsigned long long)))) return rc;
-    if ((rc = h->cand_key.ensure(slots * k * sizeof(uint64_t)))) return rc;
-    if ((rc = h->cand_row.ensure(slots * k * sizeof(uint32_t)))) return rc;
-    if ((rc = h->cand_count.ensure((size_t)n_queries * sizeof(int32_t)))) return rc;
-    p.tau = (unsigned long long*)h->tau.p;
-    p.cand_key = (uint64_t*)h->cand_key.p;
-    p.cand_row = (uint32_t*)h->cand_row.p;
-    p.cand_count = (int32_t*)h->cand_count.p;
+    p.tau = w.tau;
+    p.cand_key = w.cand_key;
+    p.cand_row = w.cand_row;
+    p.cand_count = w.cand_count;
     RAG_HIP_TRY(hipMemsetAsync(p.tau, 0, (size_t)n_queries * sizeof(unsigned long long), stream));
     RAG_HIP_TRY(hipMemsetAsync(p.cand_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
     const int64_t n_blocks = (int64_t)p.n_tiles * n_queries;
@@ -377,6 +409,97 @@ extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const 
     RAG_HIP_TRY(hipGetLastError());
     return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, (int64_t)p.n_tiles * k, k, h->row_base,
                                d_out_score, d_out_row, d_out_count, p.fault, stream);
+}
+
+}  // namespace
+
+extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
+                                   int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row,
+                                   int32_t* d_out_count, void* stream_) {
+    int rc = bm25_check_search_args(h, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count);
+    if (rc) return rc;
+    if (n_queries == 0) return RAG_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h->n_docs == 0) return bm25_empty_result(n_queries, k, d_out_score, d_out_row, d_out_count, stream);
+    const Bm25WorkBytes need = bm25_work_bytes(h, n_queries, n_terms_total, k);
+    if ((rc = h->toff.ensure(need.toff))) return rc;
+    if ((rc = h->tau.ensure(need.tau))) return rc;
+    if ((rc = h->cand_key.ensure(need.cand_key))) return rc;
+    if ((rc = h->cand_row.ensure(need.cand_row))) return rc;
+    if ((rc = h->cand_count.ensure(need.cand_count))) return rc;
+    const Bm25Work w = {(uint32_t*)h->toff.p, (unsigned long long*)h->tau.p, (uint64_t*)h->cand_key.p,
+                        (uint32_t*)h->cand_row.p, (int32_t*)h->cand_count.p};
+    return bm25_search_on(h, w, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count, stream);
+}
+
+// ---- the same search for callers that cannot allocate -----------------------------------------------
+// The work buffers live in a file-scope device array instead of the handle's grow-only buffers: nothing in
+// this entry point calls hipMalloc / hipFree or any routine that does.  Each GPU the library runs on holds
+// its own copy of the array, at its own address, until the process ends; the address is looked up once per
+// device (rag_bm25_static_setup, called by rag_init and, failing that, by the first call on a device).
+// Every call on a GPU uses that GPU's one array: two calls that overlap on one GPU (two streams, two
+// threads) race.  The array keeps the last call's contents; the thresholds and list counters, which must
+// start at zero, are cleared by every call.
+constexpr size_t BM_STATIC_BYTES = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[BM_STATIC_BYTES];
+
+namespace {
+constexpr int BM_MAX_DEVICES = 64;
+std::mutex g_static_mu;
+unsigned char* g_static_ptr[BM_MAX_DEVICES] = {};   // device address of `scratch` on each device
+}  // namespace
+
+// Look up this device's address of the static work array (the array's name itself is only a host-side
+// stand-in and must never be handed to a kernel or a memset).
+int rag_bm25_static_setup() {
+    int dev = 0;
+    RAG_HIP_TRY(hipGetDevice(&dev));
+    RAG_REQUIRE(dev >= 0 && dev < BM_MAX_DEVICES, RAG_ELIMIT, "device index %d beyond %d", dev, BM_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (g_static_ptr[dev] == nullptr) {
+        unsigned char* ptr = nullptr;
+        RAG_HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        RAG_REQUIRE(ptr != nullptr, RAG_EHIP, "hipGetSymbolAddress returned a null address for the static work array");
+        g_static_ptr[dev] = ptr;
+    }
+    return RAG_OK;
+}
+
+extern "C" int64_t rag_bm25_search_static_capacity(void) { return (int64_t)BM_STATIC_BYTES; }
+
+extern "C" int rag_bm25_search_static_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
+                                          int32_t n_terms_total, int32_t k, double* d_out_score, int64_t* d_out_row,
+                                          int32_t* d_out_count, void* stream_) {
+    int rc = bm25_check_search_args(h, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count);
+    if (rc) return rc;
+    if (n_queries == 0) return RAG_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h->n_docs == 0) return bm25_empty_result(n_queries, k, d_out_score, d_out_row, d_out_count, stream);
+    // carve the array: every piece starts on a 256-byte boundary
+    const Bm25WorkBytes need = bm25_work_bytes(h, n_queries, n_terms_total, k);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_toff = 0, o_tau = o_toff + up(need.toff), o_key = o_tau + up(need.tau),
+                 o_row = o_key + up(need.cand_key), o_cnt = o_row + up(need.cand_row), total = o_cnt + up(need.cand_count);
+    RAG_REQUIRE(total <= BM_STATIC_BYTES, RAG_ELIMIT,
+                "rag_bm25_search_static: %d queries with %d terms, k = %d over %lld documents need %zu bytes of work "
+                "space, the static array holds %zu (use rag_bm25_search_dev, or fewer queries per call)",
+                n_queries, n_terms_total, k, (long long)h->n_docs, total, (size_t)BM_STATIC_BYTES);
+    int dev = 0;
+    RAG_HIP_TRY(hipGetDevice(&dev));
+    RAG_REQUIRE(dev >= 0 && dev < BM_MAX_DEVICES, RAG_ELIMIT, "device index %d beyond %d", dev, BM_MAX_DEVICES);
+    unsigned char* ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_static_mu);
+        ptr = g_static_ptr[dev];
+    }
+    if (ptr == nullptr) {                       // rag_init was not called for this device
+        if ((rc = rag_bm25_static_setup())) return rc;
+        std::lock_guard<std::mutex> lock(g_static_mu);
+        ptr = g_static_ptr[dev];
+    }
+    const Bm25Work w = {(uint32_t*)(ptr + o_toff), (unsigned long long*)(ptr + o_tau), (uint64_t*)(ptr + o_key),
+                        (uint32_t*)(ptr + o_row), (int32_t*)(ptr + o_cnt)};
+    return bm25_search_on(h, w, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count, stream);
 }
 
 #define BM_TRY_OR_CLEAN(expr)                                                                    \

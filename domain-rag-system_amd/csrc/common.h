@@ -79,6 +79,10 @@ int rag_grant_dyn_lds(const void* kernel, size_t bytes);
 // of making the access.
 uint32_t* rag_fault_word();
 
+// Once per device, with that device current: look up the device address of the static work array behind
+// rag_bm25_search_static_dev (bm25.hip).  Called by rag_init.
+int rag_bm25_static_setup();
+
 __device__ __forceinline__ void rag_flag(uint32_t* w, uint32_t bit) {
     if (w != nullptr) atomicOr(w, bit);
 }

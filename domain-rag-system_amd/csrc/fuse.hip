@@ -722,5 +722,5 @@ extern "C" int rag_init(int device) {
         return RAG_ENODEV;
     }
     RAG_REQUIRE(rag_fault_word() != nullptr, RAG_ENOMEM, "rag_init: the fault word could not be allocated");
-    return RAG_OK;
+    return rag_bm25_static_setup();          // this device's address of the no-allocation search's work array
 }

@@ -49,6 +49,8 @@ SIGNATURES = {
     'rag_bm25_docs': (_i64, [_vp]),
     'rag_bm25_search_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'rag_bm25_search': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'rag_bm25_search_static_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'rag_bm25_search_static_capacity': (_i64, []),
     'rag_bm25_scores': (_i32, [_vp, _vp, _i32, _vp]),
     'rag_merge_topk_f32_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'rag_merge_topk_f64_dev': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -443,6 +445,23 @@ class Bm25Index:
         check(lib().rag_bm25_search_dev(self._h, _ptr(qterms, torch.int32), _ptr(qoff, torch.int32), b,
                                         int(n_terms_total), int(k), _ptr(score, torch.float64), _ptr(row, torch.int64),
                                         _ptr(cnt, torch.int32), _stream()), 'rag_bm25_search_dev')
+        return score, row, cnt
+
+    def search_static_dev(self, qterms, qoff, n_terms_total, k, out):
+        """search_dev without any device allocation (rag_bm25_search_static_dev): the work buffers come from a
+        static device array, so `out` = (scores [B,k] f64, rows [B,k] i64, counts [B] i32) must be given and
+        sizes beyond the array's capacity raise (RAG_ELIMIT).  Calls on one GPU must not overlap."""
+        import torch
+        b = qoff.shape[0] - 1
+        score, row, cnt = out
+        if int(n_terms_total) > qterms.shape[0]:
+            raise ValueError("n_terms_total exceeds the term array")
+        if tuple(score.shape) != (b, k) or tuple(row.shape) != (b, k) or tuple(cnt.shape) != (b,):
+            raise ValueError("output tensors must be [B, k], [B, k], [B]")
+        check(lib().rag_bm25_search_static_dev(self._h, _ptr(qterms, torch.int32), _ptr(qoff, torch.int32), b,
+                                               int(n_terms_total), int(k), _ptr(score, torch.float64),
+                                               _ptr(row, torch.int64), _ptr(cnt, torch.int32), _stream()),
+              'rag_bm25_search_static_dev')
         return score, row, cnt
 
     def scores(self, query_terms):

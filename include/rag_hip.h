@@ -173,6 +173,20 @@ int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_
                         double* d_out_score, int64_t* d_out_row, int32_t* d_out_count, void* stream);
 int rag_bm25_search(rag_bm25_t h, const int32_t* qterms, const int32_t* qoff, int32_t n_queries,
                     int32_t k, double* out_score, int64_t* out_row, int32_t* out_count);
+/* rag_bm25_search_dev for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments, same kernels and bit-identical results, but the work buffers (posting offsets per query term
+ * and document tile, per-query thresholds, candidate lists) come from a static device array of
+ * rag_bm25_search_static_capacity() bytes (32 MiB) that every GPU the library runs on holds until the
+ * process ends, instead of the handle's grow-only buffers: the call never reaches hipMalloc or hipFree.
+ * A search that needs more than the array holds returns RAG_ELIMIT and leaves the outputs untouched; the
+ * need is about  n_queries * ceil(n_docs / 2048) * k * 12  +  n_terms_total * (ceil(n_docs / 2048) + 1) * 4
+ * bytes (1M documents, k = 100: up to 55 queries per call).  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU race, so serialise them (one stream, or events between streams). */
+int64_t rag_bm25_search_static_capacity(void);
+int rag_bm25_search_static_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff,
+                               int32_t n_queries, int32_t n_terms_total, int32_t k,
+                               double* d_out_score, int64_t* d_out_row, int32_t* d_out_count, void* stream);
 /* Dense fp64 score vector of ONE query over all local documents (get_scores itself);
  * out_scores[n_docs] is host memory.  For parity checks and small corpora.         */
 int rag_bm25_scores(rag_bm25_t h, const int32_t* qterms, int32_t n_terms, double* out_scores);
