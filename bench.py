@@ -335,7 +335,7 @@ def main():
     mlp_ms, mlp_rows = rag_hip.enc_mlp_profile_read()
     rag_hip.enc_mlp_profile(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
 

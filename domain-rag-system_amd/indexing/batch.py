@@ -52,18 +52,25 @@ class BatchSearcher:
                  chunk_tokens: Optional[TokenStore] = None, top_k: int = 5, rerank_top_n: int = 50,
                  fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
                  ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None,
-                 ce_packed=None, ce_tokens_per_batch: int = 1 << 20, ce_token_bucket: int = 1 << 17):
+                 ce_packed=None, ce_tokens_per_batch: int = 1 << 20, ce_token_bucket: int = 1 << 17,
+                 simple_rerank: bool = False):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
         self.fusion_method, self.vw, self.bw = fusion_method, float(vector_weight), float(bm25_weight)
         self.ce_pairs_per_batch, self.ce_max_len = int(ce_pairs_per_batch), int(ce_max_len)
+        # the reference's "simple" reranker (cosine between the query embedding and each pool text's embedding,
+        # src/reranker/rerank.py:46-68) served from the resident rows: a pool entry's embedding IS its row
+        self.simple_rerank = bool(simple_rerank) and cross_encoder is None
+        if self.simple_rerank and (dense is None or getattr(dense, 'metric', None) not in (rag_hip.METRIC_COSINE, 'cosine')):
+            raise ValueError("simple_rerank needs a cosine dense index (rows stored L2-normalised)")
+        self._qvec = None
         # unpadded cross-encoder batches when the model can run them (native kernels; bfloat16 weights, or float32
         # weights with split-precision GEMMs: the reference's precision, src/reranker/rerank.py:79-84)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_sort_by_length = True
-        # sharded over RCCL: each rank embeds a slice of the queries and the slices are all-gathered
-        # (RAG_SPLIT_EMBED=0: every rank embeds all of them; =1 forces the exchange on other backends)
+        # sharded: each rank embeds a slice of the queries and the slices are all-gathered
+        # (RAG_SPLIT_EMBED=0: every rank embeds all of them)
         self.split_embed = False
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
@@ -75,16 +82,20 @@ class BatchSearcher:
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         if dist is not None:
-            want = os.environ.get('RAG_SPLIT_EMBED')
-            self.split_embed = want == '1' or (want != '0' and dist.get_backend() == 'nccl')
+            self.split_embed = os.environ.get('RAG_SPLIT_EMBED') != '0'
         self.times = StageTimes()
         self.timing = False
+        # read the device-side consistency flags after every batch and raise if a kernel met inconsistent data
+        # (synchronises the device: callers that pipeline batches switch it off and call rag_hip.check_faults()
+        # themselves when they collect results)
+        self.check_faults = hasattr(rag_hip, 'check_faults')
         self._side_stream = None
 
     # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
     @property
     def fetch_k(self):
-        return max(self.top_k, self.rerank_top_n if self.cross_encoder is not None else self.top_k)
+        reranking = self.cross_encoder is not None or self.simple_rerank
+        return max(self.top_k, self.rerank_top_n if reranking else self.top_k)
 
     def _timed(self, name, fn):
         if not self.timing:
@@ -112,9 +123,34 @@ class BatchSearcher:
             if mine is not None:
                 piece[:hi - lo] = mine
             gathered = torch.empty((self.world * per, dim), dtype=torch.float32, device=ids.device)
-            self.dist.all_gather_into_tensor(gathered, piece)
+            self._all_gather(gathered, piece)
             return gathered[:b].contiguous()
         return self._embed_local(ids, mask)
+
+    # ---- collectives ----------------------------------------------------------------
+    # Over RCCL (backend "nccl") device tensors go straight in.  Any other backend (gloo: CPU tests, and rehearsals
+    # of the multi-rank path with several ranks sharing one GPU) gets host copies: gloo's own staging of device
+    # tensors hung in such a rehearsal (both ranks inside the same small all_gather_into_tensor, every producer
+    # kernel finished), and host tensors are the path gloo is built for.
+    def _stage(self, t):
+        return t.is_cuda and self.dist.get_backend() != 'nccl'
+
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        inp = inp.contiguous()
+        if self._stage(inp):
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, inp.cpu())
+            out.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
+
+    def _all_reduce_sum(self, t: torch.Tensor):
+        if self._stage(t):
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t)
 
     def _embed_local(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         if getattr(self.bi_encoder.bert, 'native', False):
@@ -123,8 +159,9 @@ class BatchSearcher:
             return self.bi_encoder.forward_packed(p_ids, p_types, p_pos, cu, max(longest, 1), normalize=True)
         return self.bi_encoder(ids, None, mask, normalize=True).contiguous()
 
-    def _gather_merge(self, score, row, cnt, k):
-        """all-gather the per-shard lists and merge them to the global top-k."""
+    def _gather_merge(self, score, row, cnt, k, smaller_is_better=False):
+        """all-gather the per-shard lists and merge them to the global top-k (smaller_is_better: lists of
+        distances, as a Euclidean index returns them)."""
         if self.world == 1:
             return score, row, cnt
         b = score.shape[0]
@@ -133,16 +170,17 @@ class BatchSearcher:
         gs = torch.empty((self.world * b, kk), dtype=score.dtype, device=score.device)
         gr = torch.empty((self.world * b, kk), dtype=row.dtype, device=row.device)
         gc = torch.empty((self.world * b,), dtype=cnt.dtype, device=cnt.device)
-        self.dist.all_gather_into_tensor(gs, score.contiguous())
-        self.dist.all_gather_into_tensor(gr, row.contiguous())
-        self.dist.all_gather_into_tensor(gc, cnt.contiguous())
+        self._all_gather(gs, score)
+        self._all_gather(gr, row)
+        self._all_gather(gc, cnt)
         return rag_hip.merge_topk_dev(gs.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
                                       gr.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
-                                      gc.view(self.world, b).t().contiguous(), k)
+                                      gc.view(self.world, b).t().contiguous(), k, smaller_is_better=smaller_is_better)
 
     def dense_search(self, qvec: torch.Tensor, k: int):
         s, r, c = self.dense.search_dev(qvec, k)
-        return self._gather_merge(s, r, c, k)
+        euclid = getattr(self.dense, 'metric', None) in (rag_hip.METRIC_EUCLID, 'euclidean', 'euclid')
+        return self._gather_merge(s, r, c, k, smaller_is_better=euclid)
 
     def bm25_search(self, qterms: torch.Tensor, qoff: torch.Tensor, n_terms: int, k: int):
         s, r, c = self.bm25.search_dev(qterms, qoff, n_terms, k)
@@ -180,7 +218,7 @@ class BatchSearcher:
                 self._ce_padded(q_tok, q_off, my_q, my_r, plen, logits_mine)
         if self.world > 1:
             gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
-            self.dist.all_gather_into_tensor(gathered, logits_mine)
+            self._all_gather(gathered, logits_mine)
             logits = gathered[:n_pairs]
         else:
             logits = logits_mine
@@ -283,6 +321,7 @@ class BatchSearcher:
         vec = bm = None
         if self.dense is not None:
             qvec = self._timed('embed', lambda: self.embed(embed_ids, embed_mask))
+            self._qvec = qvec
             vec = self._timed('dense', lambda: self.dense_search(qvec, k_list))
         if self.bm25 is not None:
             bm = self._timed('bm25', lambda: self.bm25_search(qterms, qoff, n_terms, k_list))
@@ -296,14 +335,38 @@ class BatchSearcher:
                   torch.zeros((b,), dtype=torch.int32, device=dev))
         return self._timed('fuse', lambda: self.fuse(vec, bm, t))
 
-    def finish(self, fused, ce_q_tok=None, ce_q_off=None):
-        """Second half: cross-encoder rerank of the fused lists (or the plain cut to top_k)."""
+    def rerank_simple(self, qvec: torch.Tensor, fused_row: torch.Tensor, fused_cnt: torch.Tensor):
+        """Cosine of every fused candidate's resident embedding with its query's embedding (exact float32 dot
+        products of unit vectors, rag_dense_rescore_dev), then the per-query stable top-k.  Sharded: a row's
+        score comes from the rank that holds it (the others report 0 for it), summed over the ranks."""
+        b, t = fused_row.shape
+        scores = self.dense.rescore_dev(qvec.contiguous(), fused_row.contiguous())
+        if self.world > 1:
+            self._all_reduce_sum(scores)
+        seg_off = torch.zeros((b + 1,), dtype=torch.int32, device=fused_row.device)
+        seg_off[1:] = torch.cumsum(fused_cnt, 0)
+        if bool((fused_cnt == t).all()):
+            flat = scores.reshape(-1).contiguous()
+        else:
+            keep = torch.arange(t, device=fused_row.device)[None, :] < fused_cnt[:, None]
+            flat = scores[keep].contiguous()
+        idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
+        return idx, cnt, scores
+
+    def finish(self, fused, ce_q_tok=None, ce_q_off=None, rerank_qvec=None):
+        """Second half: rerank of the fused lists (cross-encoder, or the simple reranker from resident rows
+        with `rerank_qvec` = embeddings of the ORIGINAL queries when they differ from the retrieval ones,
+        scripts/query.py:134-136,160), or the plain cut to top_k."""
         pos, row, score, cnt = fused
         out = {'fused_row': row, 'fused_score': score, 'fused_count': cnt}
-        if self.cross_encoder is None:
+        if self.cross_encoder is None and not self.simple_rerank:
             out.update(rows=row[:, :self.top_k], scores=score[:, :self.top_k], count=torch.clamp(cnt, max=self.top_k))
             return out
-        idx, rc, logits = self._timed('rerank', lambda: self.rerank(ce_q_tok, ce_q_off, row, cnt))
+        if self.cross_encoder is None:
+            qv = rerank_qvec if rerank_qvec is not None else self._qvec
+            idx, rc, logits = self._timed('rerank', lambda: self.rerank_simple(qv, row, cnt))
+        else:
+            idx, rc, logits = self._timed('rerank', lambda: self.rerank(ce_q_tok, ce_q_off, row, cnt))
         safe = idx.clamp(min=0).long()
         out.update(rows=torch.where(idx >= 0, torch.gather(row, 1, safe), torch.full_like(safe, -1)),
                    scores=torch.gather(score, 1, safe), rerank_score=torch.gather(logits, 1, safe), count=rc,
@@ -313,7 +376,10 @@ class BatchSearcher:
     def search(self, embed_ids, embed_mask, qterms, qoff, n_terms, ce_q_tok=None, ce_q_off=None):
         """One batch through the whole path.  Returns dict of device tensors:
         rows [B, top_k] (global), fused_score f64 [B, top_k], rerank_score f32 (if reranked)."""
-        return self.finish(self.retrieve(embed_ids, embed_mask, qterms, qoff, n_terms), ce_q_tok, ce_q_off)
+        out = self.finish(self.retrieve(embed_ids, embed_mask, qterms, qoff, n_terms), ce_q_tok, ce_q_off)
+        if self.check_faults:
+            rag_hip.check_faults()
+        return out
 
     def search_many(self, batches):
         """Several batches, software-pipelined over two HIP streams: while the cross-encoder
@@ -346,4 +412,6 @@ class BatchSearcher:
                 nxt = launch(batches[i + 1])
             main.wait_event(ev)
             outs.append(self.finish(fused, *b[5:7]))
+        if self.check_faults:
+            rag_hip.check_faults()
         return outs

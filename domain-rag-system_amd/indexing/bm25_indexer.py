@@ -14,9 +14,11 @@ Arithmetic contract (rank_bm25 0.2.x ``BM25Okapi``, restated):
 Ranking: score descending, equal scores by row index descending (the order a stable
 ``argsort`` followed by ``[::-1]`` produces; upstream's order among ties is unspecified).
 """
+import io
 import math
 import pickle
 import re
+import warnings
 from pathlib import Path
 
 import numpy as np
@@ -30,6 +32,52 @@ import rag_hip
 
 _TOKEN = re.compile(r'\b\w+\b')
 _EPSILON = 0.25
+
+
+class _ForeignObject:
+    """Inert stand-in for an instance of a class this package does not have (a pickled
+    ``rank_bm25.BM25Okapi``, a chunk object of another package): it keeps the instance's attribute
+    dictionary and runs none of the original class's code."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple) and len(state) == 2:          # (dict, slots)
+            for part in state:
+                if isinstance(part, dict):
+                    self.__dict__.update(part)
+
+    def to_dict(self):                                               # chunk objects
+        return {k: self.__dict__.get(k, d) for k, d in (('chunk_id', ''), ('doc_id', ''), ('source', ''),
+                                                        ('chunk_type', ''), ('text', ''), ('metadata', {}))}
+
+
+class _IndexUnpickler(pickle.Unpickler):
+    """Unpickler for ``bm25_index.pkl`` that executes nothing from the file: only builtin containers,
+    numpy array / scalar reconstruction and (as inert attribute bags) the foreign classes a pickle written by
+    the reference holds (``rank_bm25.BM25Okapi``, ``...chunker.Chunk``).  Any other global is refused."""
+
+    _SAFE = {
+        ('builtins', n) for n in ('dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'complex', 'str',
+                                  'bytes', 'bytearray', 'bool', 'slice', 'range', 'object')
+    } | {('collections', 'OrderedDict'), ('collections', 'defaultdict'), ('copyreg', '_reconstructor')}
+    _NUMPY = {'_reconstruct', 'scalar', 'ndarray', 'dtype', '_frombuffer'}
+
+    def find_class(self, module, name):
+        if (module, name) in self._SAFE:
+            return super().find_class(module, name)
+        if module in ('numpy', 'numpy.core.multiarray', 'numpy._core.multiarray', 'numpy.core.numeric',
+                      'numpy._core.numeric') and name in self._NUMPY:
+            return super().find_class(module, name)
+        if module.startswith('numpy') and name.startswith(('float', 'int', 'uint', 'bool')):     # numpy.float64 ...
+            return super().find_class(module, name)
+        if (module.split('.')[0] == 'rank_bm25' and name.startswith('BM25')) or (module.endswith('chunker') and name == 'Chunk'):
+            return _ForeignObject
+        raise pickle.UnpicklingError(f"bm25 index file refers to {module}.{name}, which this loader does not admit "
+                                     "(only plain containers, numpy arrays and the reference's BM25Okapi / Chunk objects)")
 
 
 class Bm25Arrays:
@@ -214,8 +262,13 @@ class BM25Indexer:
         if self.bm25 is None:
             raise ValueError("Index not built. Call index_chunks() first.")
         ids = [self.term_ids(self.tokenize(q)) for q in queries]
+        if int(k) > rag_hip.MAX_K:
+            warnings.warn(f"BM25 search asked for {int(k)} results per query; the kernels return at most "
+                          f"{rag_hip.MAX_K}, so the list is cut there", RuntimeWarning, stacklevel=2)
         k = min(int(k), rag_hip.MAX_K)
-        return self._device_index.search(ids, k)
+        out = self._device_index.search(ids, k)
+        rag_hip.check_faults()               # a kernel that met inconsistent data flags it instead of faulting
+        return out
 
     def _format(self, idx, score):
         c = self.chunks[idx]
@@ -276,8 +329,11 @@ class BM25Indexer:
         if not filepath.exists():
             raise FileNotFoundError(f"Index file not found: {filepath}")
         with open(filepath, 'rb') as f:
-            data = pickle.load(f)           # a file this class wrote
-        self.chunks = data['chunks']
+            # executes nothing from the file: see _IndexUnpickler
+            data = _IndexUnpickler(io.BytesIO(f.read())).load()
+        if not isinstance(data, dict) or not {'chunks', 'tokenized_corpus', 'k1', 'b'} <= set(data):
+            raise ValueError(f"{filepath} is not a BM25 index file (keys 'bm25', 'chunks', 'tokenized_corpus', 'k1', 'b')")
+        self.chunks = [c.to_dict() if isinstance(c, _ForeignObject) else c for c in data['chunks']]
         self.tokenized_corpus = data['tokenized_corpus']
         self.k1 = data['k1']
         self.b = data['b']
@@ -287,7 +343,9 @@ class BM25Indexer:
                                    s['avgdl'], s['k1'], s['b'])
             self._upload()
         elif self.tokenized_corpus:
-            # a pickle from another writer: rebuild from its token lists
+            # a file the reference wrote (its 'bm25' entry is a pickled rank_bm25.BM25Okapi, loaded as an inert
+            # attribute bag): the index is rebuilt from the token lists the file carries, which is what that
+            # object was built from (reference src/indexing/bm25_indexer.py:102-106, :170-176)
             self._build(self.tokenized_corpus)
         else:
             self.bm25 = None

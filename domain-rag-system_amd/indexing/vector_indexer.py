@@ -71,6 +71,7 @@ class VectorIndexer:
         self._payloads = []
         self._canon = None
         self._code_cols, self._row_filter = {}, None   # per-key categorical codes for device-side filters
+        self._text_rows = None              # text -> first row holding it (rows_of_texts)
         self._created = False
 
     # ---- store management ------------------------------------------------------------
@@ -82,6 +83,7 @@ class VectorIndexer:
             self._index.close()
         self._index, self._payloads, self._canon = None, [], None
         self._code_cols, self._row_filter = {}, None
+        self._text_rows = None
 
     def create_collection(self, force_recreate: bool = True):
         d = self._dir()
@@ -236,14 +238,44 @@ class VectorIndexer:
         """Batched core: [B, dim] query vectors -> (scores [B,k] f32, rows [B,k], counts)."""
         if not self._attach():
             raise ValueError(f"Collection {self.collection_name} not found")
+        if int(k) > rag_hip.MAX_K:
+            import warnings
+            warnings.warn(f"vector search asked for {int(k)} results per query; the kernels return at most "
+                          f"{rag_hip.MAX_K}, so the list is cut there", RuntimeWarning, stacklevel=2)
         k = min(int(k), rag_hip.MAX_K)
         if not filters:
-            return self._index.search(self.prepare_queries(query_vectors), k)
-        import torch
-        mask = self.row_mask_dev(filters)
-        q = torch.from_numpy(self.prepare_queries(query_vectors)).to(mask.device)
-        score, row, cnt = self._index.search_dev(q, k, row_mask=mask)
-        return score.cpu().numpy(), row.cpu().numpy(), cnt.cpu().numpy()
+            out = self._index.search(self.prepare_queries(query_vectors), k)
+        else:
+            import torch
+            mask = self.row_mask_dev(filters)
+            q = torch.from_numpy(self.prepare_queries(query_vectors)).to(mask.device)
+            score, row, cnt = self._index.search_dev(q, k, row_mask=mask)
+            out = score.cpu().numpy(), row.cpu().numpy(), cnt.cpu().numpy()
+        rag_hip.check_faults()               # a kernel that met inconsistent data flags it instead of faulting
+        return out
+
+    def rows_of_texts(self, texts: List[str]) -> List[int]:
+        """Row that holds each text's embedding, -1 for a text the collection does not hold.  Rows with equal
+        text have equal embeddings (the embedder is deterministic), so the first such row stands for all."""
+        if not self._attach():
+            return [-1] * len(texts)
+        if self._text_rows is None:
+            table = {}
+            for i, p in enumerate(self._payloads):
+                table.setdefault(p['text'], i)
+            self._text_rows = table
+        return [self._text_rows.get(t, -1) for t in texts]
+
+    def cosine_to_rows(self, query_vector: np.ndarray, rows: List[int]) -> np.ndarray:
+        """Cosine similarity between one query vector and the stored embeddings of `rows` (float32), computed
+        from the resident matrix (rag_dense_rescore).  Only for cosine collections, whose rows are stored
+        L2-normalised: the float32 dot product with the normalised query is the cosine."""
+        if self.distance_metric != 'cosine':
+            raise ValueError("cosine_to_rows needs a cosine collection (rows stored L2-normalised)")
+        q = self.prepare_queries(np.asarray(query_vector, np.float32).reshape(1, -1))
+        out = self._index.rescore(q, np.asarray(rows, np.int64).reshape(1, -1))[0]
+        rag_hip.check_faults()
+        return out
 
     def format_hit(self, row: int, score: float) -> Dict:
         p = self._payloads[row]

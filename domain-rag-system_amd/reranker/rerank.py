@@ -63,17 +63,49 @@ class BaseReranker:
 
 
 class SimpleSimilarityReranker(BaseReranker):
-    """Cosine similarity between the query embedding and each pool text's embedding."""
+    """Cosine similarity between the query embedding and each pool text's embedding (reference
+    ``src/reranker/rerank.py:46-68``, which embeds the query and every pool text per call).
 
-    def __init__(self, embedder: Optional[MedicalEmbedder] = None, top_n: int = 50):
+    With ``vector_indexer`` (a cosine collection built with the same embedder) the pool texts are not embedded
+    again: a text the collection holds already has its embedding resident in HBM, so its score is one exact
+    float32 dot product with the (normalised) query embedding (``rag_dense_rescore``).  Only the query, and any
+    text the collection does not hold, go through the encoder."""
+
+    def __init__(self, embedder: Optional[MedicalEmbedder] = None, top_n: int = 50, vector_indexer=None):
         super().__init__(top_n=top_n, name="simple-sim")
         self.embedder = embedder or MedicalEmbedder()
         self.dim = self.embedder.embedding_dim
+        self.vector_indexer = vector_indexer
+        if vector_indexer is not None and (vector_indexer.distance_metric != 'cosine'
+                                           or vector_indexer.embedder is not self.embedder):
+            raise ValueError("the resident-row route needs a cosine collection built with this reranker's embedder")
 
     def score_pairs(self, pairs: Iterable[Tuple[str, str]]) -> List[float]:
         pairs = list(pairs)
         if not pairs:
             return []
+        if self.vector_indexer is not None:
+            return self._score_from_rows(pairs)
+        return self._score_by_embedding(pairs[0][0], [t for _, t in pairs])
+
+    def _score_from_rows(self, pairs):
+        vi = self.vector_indexer
+        texts = [t for _, t in pairs]
+        rows = vi.rows_of_texts(texts)
+        out = [0.0] * len(pairs)
+        held = [i for i, r in enumerate(rows) if r >= 0]
+        foreign = [i for i, r in enumerate(rows) if r < 0]
+        if held:
+            q = self.embedder.encode(pairs[0][0])[0]
+            for i, s in zip(held, vi.cosine_to_rows(q, [rows[i] for i in held])):
+                out[i] = float(s)
+        if foreign:
+            for i, s in zip(foreign, self._score_by_embedding(pairs[0][0], [texts[i] for i in foreign])):
+                out[i] = s
+        return out
+
+    def _score_by_embedding(self, query: str, texts: List[str]) -> List[float]:
+        pairs = [(query, t) for t in texts]
         e = self.embedder
         seqs = [e.tokenize(pairs[0][0])] + [e.tokenize(t) for _, t in pairs]
         emb = e.encode_tokens(seqs, normalize=True)
@@ -139,9 +171,15 @@ class CrossEncoderReranker(BaseReranker):
 
 def build_reranker(kind: Literal["none", "simple", "crossencoder"] = "simple", top_n: int = 50,
                    cross_model: str = "cross-encoder/ms-marco-MiniLM-L-6-v2",
-                   embedder: Optional[MedicalEmbedder] = None) -> Optional[BaseReranker]:
+                   embedder: Optional[MedicalEmbedder] = None, vector_indexer=None) -> Optional[BaseReranker]:
+    """The reference's factory (``src/reranker/rerank.py:87-101``) plus ``vector_indexer``: given a cosine
+    collection built with ``embedder``, the simple reranker scores pool texts from its resident rows."""
     if kind == "none":
         return None
     if kind == "crossencoder":
         return CrossEncoderReranker(model_name=cross_model, top_n=top_n)
-    return SimpleSimilarityReranker(embedder=embedder, top_n=top_n)
+    if vector_indexer is not None and (vector_indexer.distance_metric != 'cosine'
+                                       or (embedder is not None and vector_indexer.embedder is not embedder)):
+        vector_indexer = None
+    return SimpleSimilarityReranker(embedder=embedder or (vector_indexer.embedder if vector_indexer else None),
+                                    top_n=top_n, vector_indexer=vector_indexer)

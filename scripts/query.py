@@ -67,7 +67,7 @@ def main(args):
                             vector_weight=args.vector_weight, bm25_weight=args.bm25_weight, filters=args.filters)
     if args.reranker_kind != 'none' and results:
         rr = build_reranker(kind=args.reranker_kind, top_n=args.rerank_top_n, cross_model=args.cross_model,
-                            embedder=hybrid.vector_indexer.embedder)
+                            embedder=hybrid.vector_indexer.embedder, vector_indexer=hybrid.vector_indexer)
         if rr is not None:
             results = rr.rerank(args.query, results, top_k=args.top_k)
 

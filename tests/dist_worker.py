@@ -1,5 +1,6 @@
-"""Worker for the world_size-2 gloo test (TEST INFRASTRUCTURE): one rank of the row-sharded
-batched query path, GPU entry points replaced by the oracle-backed doubles."""
+"""Worker for the world_size-2 gloo tests (TEST INFRASTRUCTURE): one rank of the row-sharded
+batched query path.  On the CPU the GPU entry points are replaced by the oracle-backed doubles; with
+device 'cuda' the real kernels run, every rank on GPU 0 (the exchange still goes over gloo)."""
 import os
 import sys
 
@@ -32,13 +33,13 @@ def make_world(n=600, dim=64, vocab=300, seed=0):
     return dict(corpus=corpus, term=term, doc=doc, ln=ln, v=v, canon=canon, tok=tok, off=off, q_ids=q_ids, bm_q=bm_q)
 
 
-def run_rank(rank, world, port, out_path, fusion='rrf'):
+def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranker='cross', device='cpu'):
     import types
     from tests import fake_backend
     import rag_hip
-    for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
+    for name in () if device != 'cpu' else ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
                  'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev',
-                 'ce_pack_dev'):
+                 'ce_pack_dev', 'check_faults'):
         setattr(rag_hip, name, getattr(fake_backend, name))
     from indexing import bert
     from indexing.batch import BatchSearcher, TokenStore
@@ -58,24 +59,30 @@ def run_rank(rank, world, port, out_path, fusion='rrf'):
         df = np.bincount(np.unique(w['term'] * n + w['doc']) // n, minlength=w['v'])
         stats = dict(df=df, total_len=int(w['ln'].sum()), n_docs=n)
     arr = build_arrays(w['term'][sel], w['doc'][sel] - lo, w['ln'][lo:hi], w['v'], 1.5, 0.75, global_stats=stats)
-    dense = rag_hip.DenseIndex(w['corpus'][lo:hi], row_base=lo)
+    dense = rag_hip.DenseIndex(w['corpus'][lo:hi], metric=metric, row_base=lo)
     bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, hi - lo, row_base=lo)
-    bi, _, _ = bert.load_model('random:tiny', 'bi', 'cpu')
-    ce, _, _ = bert.load_model('random:tiny', 'cross', 'cpu')
-    s = BatchSearcher(dense, bm25, canon=torch.from_numpy(w['canon']), bi_encoder=bi, cross_encoder=ce,
-                      chunk_tokens=TokenStore(torch.from_numpy(w['tok']), torch.from_numpy(w['off'])),
+    bi, _, _ = bert.load_model('random:tiny', 'bi', device)
+    ce, _, _ = bert.load_model('random:tiny', 'cross', device)
+    if device != 'cpu':
+        rag_hip.init(0)
+    dv = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(device)
+    s = BatchSearcher(dense, bm25, canon=dv(w['canon']), bi_encoder=bi,
+                      cross_encoder=ce if reranker == 'cross' else None, simple_rerank=reranker == 'simple',
+                      chunk_tokens=TokenStore(dv(w['tok']), dv(w['off'])),
                       top_k=4, rerank_top_n=11, fusion_method=fusion, vector_weight=0.6, bm25_weight=0.4,
                       ce_pairs_per_batch=16, dist=dist)
     qterms, qoff = rag_hip.Bm25Index.flatten(w['bm_q'])
-    ids = torch.from_numpy(w['q_ids'])
-    ce_tok = torch.from_numpy(w['q_ids'][:, 1:7].astype(np.int32).reshape(-1).copy())
-    ce_off = torch.arange(ids.shape[0] + 1, dtype=torch.int64) * 6
-    out = s.search(ids, torch.ones_like(ids), torch.from_numpy(qterms), torch.from_numpy(qoff), int(qoff[-1]),
+    ids = dv(w['q_ids'])
+    ce_tok = dv(w['q_ids'][:, 1:7].astype(np.int32).reshape(-1).copy())
+    ce_off = dv(torch.arange(ids.shape[0] + 1, dtype=torch.int64) * 6)
+    qterms, qoff = dv(qterms), dv(qoff)
+    s.split_embed = False                  # first every rank embeds every query ...
+    out = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]),
                    ce_tok, ce_off)
     if world > 1:
-        # the optional exchange of query embeddings (each rank embeds a slice) must give the same answer
+        # ... then the default: each rank embeds a slice and the slices are exchanged; same answer
         s.split_embed = True
-        again = s.search(ids, torch.ones_like(ids), torch.from_numpy(qterms), torch.from_numpy(qoff), int(qoff[-1]),
+        again = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]),
                          ce_tok, ce_off)
         for k, v in out.items():
             if torch.is_tensor(v):
@@ -84,11 +91,12 @@ def run_rank(rank, world, port, out_path, fusion='rrf'):
                 else:
                     assert torch.equal(v, again[k]), k
     if rank == 0:
-        torch.save({k: v for k, v in out.items()}, out_path)
+        torch.save({k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}, out_path)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    run_rank(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    run_rank(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5],
+             sys.argv[6] if len(sys.argv) > 6 else 'cosine', sys.argv[7] if len(sys.argv) > 7 else 'cross', sys.argv[8] if len(sys.argv) > 8 else 'cpu')

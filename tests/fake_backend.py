@@ -50,6 +50,9 @@ class DenseIndex:
         s, r, c = self.search(queries.numpy(), k, None if row_mask is None else row_mask.numpy())
         return torch.from_numpy(s), torch.from_numpy(r), torch.from_numpy(c)
 
+    def rescore_dev(self, queries, cand_rows):
+        return torch.from_numpy(self.rescore(queries.numpy(), cand_rows.numpy()))
+
     def rescore(self, queries, cand_rows):
         q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim)
         c = np.asarray(cand_rows, np.int64).reshape(q.shape[0], -1)
@@ -265,12 +268,16 @@ class RowFilter:
         return torch.from_numpy(mask)
 
 
+def check_faults():
+    """The doubles index nothing with unchecked device data: nothing to report."""
+
+
 def install(monkeypatch):
     """Replace the GPU entry points of the imported ``rag_hip`` module with the doubles."""
     import rag_hip
     for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
                  'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev',
-                 'RowFilter'):
+                 'RowFilter', 'check_faults'):
         monkeypatch.setattr(rag_hip, name, globals()[name])
     # the device-side index build is replaced by the host counting it is tested against on the GPU
     from indexing import bm25_indexer

@@ -94,6 +94,18 @@ TOKENIZE_CASES = [
     "tabs\tand\nnewlines\r\nhere  double  spaces",
 ]
 
+NORMALIZE_CASES = [
+    "Pt w/ MI & HTN on ACE inhibitor; hx of T2DM, HbA1c 8.1",
+    "What are the side effects of Tylenol and advil for a heart attack?",
+    "high blood pressure treatment w/o NSAID",
+    "COPD vs emphysema: flu shot? GERD / acid reflux / heartburn",
+    "mi amigo has dm and a Stroke",          # case-insensitive whole-word matches
+    "MIxed tokens HTNx xMI DM2",             # no whole-word match
+    "",
+    "generalized anxiety disorder (GAD) and MDD; sugar disease",
+]
+NORMALIZE_DRUG_MAPPING = {"acetaminophen": ["Tylenol", "Panadol"], "ibuprofen": ["Advil", "Motrin"]}
+
 RERANK_CASES = {
     # name: (results as (cid, fused score, extra), scores by position, top_n, top_k)
     'basic': ([('a', 0.03, {'fusion_method': 'rrf'}), ('b', 0.02, {'fusion_method': 'rrf'}),
@@ -134,6 +146,18 @@ def main():
     out['abbreviation_keys'] = list(bm.normalizer.abbreviations.keys())
     for text in TOKENIZE_CASES:
         out['tokenize'].append({'text': text, 'expected': bm.tokenize(text)})
+
+    # query rewriting in front of retrieval (scripts/query.py:122-136 calls normalize_text through the
+    # query preprocessor): default tables, then with a brand -> generic mapping
+    out['normalize'] = []
+    for mapping in ({}, NORMALIZE_DRUG_MAPPING):
+        nz = MedicalTermNormalizer()
+        nz.drug_mapping = dict(mapping)
+        for text in NORMALIZE_CASES:
+            for expand in (True, False):
+                out['normalize'].append({'text': text, 'drug_mapping': mapping, 'expand_abbreviations': expand,
+                                         'expected': nz.normalize_text(text, expand_abbreviations=expand),
+                                         'terms': nz.extract_medical_terms(text) if text else None})
 
     class TableReranker(BaseReranker):
         def __init__(self, table, top_n):

@@ -19,10 +19,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, out_path, fusion):
+def _run(world, out_path, fusion, metric='cosine', reranker='cross', device='cpu'):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
-                               out_path, fusion]) for r in range(world)]
+                               out_path, fusion, metric, reranker, device]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     return torch.load(out_path, weights_only=True)
@@ -38,3 +38,36 @@ def test_two_shards_equal_one(tmp_path, fusion):
     assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
     assert torch.allclose(one['rerank_score'], two['rerank_score'], atol=1e-5)
     assert one['rows'].shape == (9, 4) and int(one['count'].min()) == 4
+
+
+def test_two_shards_equal_one_with_a_euclidean_index(tmp_path):
+    """Distances are smaller-is-better: the shard merge must keep each query's k SMALLEST distances."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'euclidean')
+    two = _run(2, str(tmp_path / 'two.pt'), 'rrf', 'euclidean')
+    assert torch.equal(one['fused_row'], two['fused_row'])
+    assert torch.equal(one['fused_score'], two['fused_score'])
+    assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
+    cos = _run(1, str(tmp_path / 'cos.pt'), 'rrf', 'cosine')
+    assert one['rows'].shape == cos['rows'].shape        # (unit vectors: both metrics rank alike, both paths run)
+
+
+def test_two_shards_equal_one_with_the_simple_reranker(tmp_path):
+    """Simple reranker from resident rows: each rank scores the pool rows it holds, the scores are summed."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'cosine', 'simple')
+    two = _run(2, str(tmp_path / 'two.pt'), 'rrf', 'cosine', 'simple')
+    assert torch.equal(one['fused_row'], two['fused_row'])
+    assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
+    assert torch.equal(one['rerank_score'], two['rerank_score'])          # the same float32 dot products
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('reranker', ['cross', 'simple'])
+def test_two_ranks_on_one_gpu_equal_one_with_the_real_kernels(tmp_path, reranker):
+    """The same comparison with librag_hip's kernels: two processes share GPU 0, each holds half of the rows,
+    the exchanges (query-embedding slices, per-shard lists, logits / rescored rows) go over gloo."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'cosine', reranker, 'cuda')
+    two = _run(2, str(tmp_path / 'two.pt'), 'rrf', 'cosine', reranker, 'cuda')
+    assert torch.equal(one['fused_row'], two['fused_row'])
+    assert torch.equal(one['fused_score'], two['fused_score'])
+    assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
+    assert torch.allclose(one['rerank_score'], two['rerank_score'], atol=1e-5)

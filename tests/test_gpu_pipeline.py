@@ -151,6 +151,64 @@ def test_simple_reranker_scores_from_resident_rows():
     assert np.allclose(by_text, by_rows, atol=1e-5)
 
 
+def test_simple_reranker_class_uses_resident_rows():
+    from indexing import MedicalEmbedder, VectorIndexer
+    from reranker import SimpleSimilarityReranker, build_reranker
+    chunks = make_chunks(400, seed=43)
+    e = MedicalEmbedder(model_name='random:tiny', device='cuda')
+    vi = VectorIndexer('c', e, use_in_memory=True)
+    vi.create_collection()
+    vi.index_chunks(chunks)
+    plain = SimpleSimilarityReranker(embedder=e, top_n=50)
+    fast = build_reranker('simple', top_n=50, embedder=e, vector_indexer=vi)
+    q = 'liver warning adults'
+    results = vi.search(q, top_k=40) + [{'chunk_id': 'x', 'text': 'unseen text about kidney', 'score': 0.0}]
+    a = plain.score_pairs([(q, r['text']) for r in results])
+    b = fast.score_pairs([(q, r['text']) for r in results])
+    assert np.allclose(a, b, atol=2e-6)
+    got = [r['chunk_id'] for r in fast.rerank(q, [dict(r) for r in results], top_k=10)]
+    want = [r['chunk_id'] for r in plain.rerank(q, [dict(r) for r in results], top_k=10)]
+    assert got == want
+
+
+def test_batched_simple_rerank_matches_the_oracle():
+    """BatchSearcher(simple_rerank=True): hybrid + RRF, then the reference's simple reranker (cosine of the
+    query embedding with every pool entry's embedding, rerank.py:46-68) from the resident rows."""
+    import rag_hip
+    from indexing import bert
+    from indexing.batch import BatchSearcher
+    from indexing.bm25_indexer import build_arrays
+    from oracle.rerank_ref import rerank_order_ref
+    dev = torch.device('cuda:0')
+    n, dim, vocab, b, top_n = 30000, 64, 2000, 40, 30
+    corpus = synth.dense_corpus(n, dim, seed=5)
+    term, doc, ln = synth.sparse_corpus(n, vocab, seed=6, mean_len=25)
+    arr = build_arrays(term, doc, ln, vocab, 1.5, 0.75)
+    dense = rag_hip.DenseIndex(corpus)
+    bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n)
+    bi, _, _ = bert.load_model('random:tiny', 'bi', dev)
+    rng = np.random.default_rng(8)
+    q_ids = np.zeros((b, 12), np.int64)
+    q_ids[:, 0], q_ids[:, 11] = 101, 102
+    q_ids[:, 1:11] = rng.integers(1000, 4096, size=(b, 10))
+    qterms, qoff = rag_hip.Bm25Index.flatten(synth.sparse_queries(term, doc, ln, vocab, b, seed=9))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    s = BatchSearcher(dense, bm25, canon=None, bi_encoder=bi, top_k=5, rerank_top_n=top_n, simple_rerank=True)
+    assert s.fetch_k == top_n
+    out = s.search(t(q_ids), t(np.ones((b, 12), np.int64)), t(qterms), t(qoff), int(qoff[-1]))
+    torch.cuda.synchronize()
+    qv = s.embed(t(q_ids), t(np.ones((b, 12), np.int64))).cpu().numpy()
+    fused = out['fused_row'].cpu().numpy()
+    for i in range(b):
+        cos = (corpus[fused[i]] @ qv[i]).astype(np.float32)
+        got = out['logits'][i].cpu().numpy()
+        assert np.abs(got - cos).max() < 1e-6
+        order = rerank_order_ref([float(x) for x in got], 5)
+        assert out['rows'][i].cpu().tolist() == [int(fused[i][p]) for p in order]
+    with pytest.raises(ValueError):
+        BatchSearcher(rag_hip.DenseIndex(corpus[:100], metric='dot'), None, bi_encoder=bi, simple_rerank=True)
+
+
 def test_pipelined_batches_equal_one_by_one():
     """search_many (retrieval of batch i+1 on a side stream under the rerank of batch i) returns
     bit for bit what search returns batch by batch."""

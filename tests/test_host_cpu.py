@@ -43,6 +43,19 @@ def test_tokenizer_matches_reference_fixture(case):
     assert BM25Indexer().tokenize(case['text']) == case['expected']
 
 
+@pytest.mark.parametrize('case', GOLD['normalize'], ids=lambda c: '%s|%s|%s' % (c['text'][:16], bool(c['drug_mapping']),
+                                                                            c['expand_abbreviations']))
+def test_query_rewriting_matches_reference_fixture(case):
+    """MedicalTermNormalizer.normalize_text / extract_medical_terms against the reference's own outputs
+    (src/preprocessing/medical_term_normalizer.py; reached from scripts/query.py:122-136)."""
+    from preprocessing import MedicalTermNormalizer
+    nz = MedicalTermNormalizer()
+    nz.drug_mapping = dict(case['drug_mapping'])
+    assert nz.normalize_text(case['text'], expand_abbreviations=case['expand_abbreviations']) == case['expected']
+    if case['terms'] is not None:
+        assert nz.extract_medical_terms(case['text']) == case['terms']
+
+
 def test_tokenizer_keeps_single_character_abbreviation_keys():
     from indexing.bm25_indexer import BM25Indexer
     from preprocessing import MedicalTermNormalizer
@@ -86,6 +99,81 @@ def test_bm25_indexer_matches_oracle(backend, tmp_path):
     assert ix2.search('aspirin pain', top_k=5) == ix.search('aspirin pain', top_k=5)
     with pytest.raises(FileNotFoundError):
         ix2.load(str(tmp_path / 'nope.pkl'))
+
+
+def test_bm25_load_reads_a_reference_written_pickle_without_running_its_code(backend, tmp_path, monkeypatch):
+    """The reference pickles {'bm25': <rank_bm25.BM25Okapi instance>, 'chunks', 'tokenized_corpus', 'k1', 'b'}
+    (src/indexing/bm25_indexer.py:170-176).  rank_bm25 is not installed: the loader admits that class (and the
+    chunker's Chunk objects) only as inert attribute bags, rebuilds the index from the token lists, and refuses any
+    other global - nothing in the file is executed."""
+    import pickle
+    import sys
+    import types
+    from indexing.bm25_indexer import BM25Indexer
+    chunks = make_chunks(120)
+    ours = BM25Indexer(k1=1.3, b=0.7)
+    ours.index_chunks(chunks)
+
+    # a stand-in for the upstream class, present only while the file is written
+    mod = types.ModuleType('rank_bm25')
+
+    class BM25Okapi:
+        def __init__(self, corpus, k1, b):
+            self.k1, self.b, self.epsilon, self.corpus_size = k1, b, 0.25, len(corpus)
+            self.doc_len = [len(d) for d in corpus]
+            self.avgdl = sum(self.doc_len) / max(len(corpus), 1)
+            self.doc_freqs = [{w: d.count(w) for w in set(d)} for d in corpus]
+            self.idf = {w: 0.5 for d in corpus for w in d}
+            self.tokenizer = None
+
+        def __reduce_ex__(self, protocol):       # what object.__reduce_ex__ gives a plain instance
+            return object.__reduce_ex__(self, protocol)
+    BM25Okapi.__module__, BM25Okapi.__qualname__ = 'rank_bm25', 'BM25Okapi'
+    mod.BM25Okapi = BM25Okapi
+    chunker = types.ModuleType('src.preprocessing.chunker')
+
+    class Chunk:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    Chunk.__module__, Chunk.__qualname__ = 'src.preprocessing.chunker', 'Chunk'
+    chunker.Chunk = Chunk
+    monkeypatch.setitem(sys.modules, 'rank_bm25', mod)
+    for parent in ('src', 'src.preprocessing'):
+        if parent not in sys.modules:
+            monkeypatch.setitem(sys.modules, parent, types.ModuleType(parent))
+    monkeypatch.setitem(sys.modules, 'src.preprocessing.chunker', chunker)
+    toks = [ours.tokenize(c['text']) for c in chunks]
+    objs = [Chunk(**c) if i % 2 else c for i, c in enumerate(chunks)]        # both chunk spellings
+    p = tmp_path / 'bm25_index.pkl'
+    with open(p, 'wb') as f:
+        pickle.dump({'bm25': BM25Okapi(toks, 1.3, 0.7), 'chunks': objs, 'tokenized_corpus': toks, 'k1': 1.3, 'b': 0.7}, f)
+    monkeypatch.delitem(sys.modules, 'rank_bm25')
+    monkeypatch.delitem(sys.modules, 'src.preprocessing.chunker')
+    with pytest.raises(ModuleNotFoundError):
+        with open(p, 'rb') as f:
+            pickle.load(f)                       # the plain loader needs the package
+    ix = BM25Indexer()
+    ix.load(str(p))
+    assert (ix.k1, ix.b) == (1.3, 0.7) and len(ix.chunks) == 120 and all(isinstance(c, dict) for c in ix.chunks)
+    for q in ('aspirin pain', 'liver the the', 'zzz'):
+        assert ix.search(q, top_k=7) == ours.search(q, top_k=7)
+
+    # a file that names any other global is refused before anything runs
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo should-never-run > %s' % (tmp_path / 'pwned'),))
+    bad = tmp_path / 'bad.pkl'
+    with open(bad, 'wb') as f:
+        pickle.dump({'bm25': Evil(), 'chunks': [], 'tokenized_corpus': [], 'k1': 1.5, 'b': 0.75}, f)
+    with pytest.raises(pickle.UnpicklingError, match='does not admit'):
+        BM25Indexer().load(str(bad))
+    assert not (tmp_path / 'pwned').exists()
+    other = tmp_path / 'other.pkl'
+    with open(other, 'wb') as f:
+        pickle.dump([1, 2, 3], f)
+    with pytest.raises(ValueError, match='not a BM25 index file'):
+        BM25Indexer().load(str(other))
 
 
 def test_bm25_accepts_chunk_objects(backend):
@@ -248,6 +336,34 @@ def test_rerankers_and_factory(backend):
     with pytest.raises(FileNotFoundError):          # no silent switch to another reranker
         build_reranker('crossencoder', cross_model='cross-encoder/not-in-cache')
     assert BaseReranker().rerank('q', []) == []
+
+
+def test_simple_reranker_from_resident_rows_equals_re_embedding(backend):
+    """SimpleSimilarityReranker(vector_indexer=...) scores pool texts from the stored embeddings; texts the
+    collection does not hold are embedded as before.  Same scores, same order (reference rerank.py:46-68)."""
+    from indexing import VectorIndexer
+    from reranker import build_reranker, SimpleSimilarityReranker
+    e = _embedder()
+    chunks = make_chunks(200, seed=5)
+    vi = VectorIndexer('c', e, use_in_memory=True)
+    vi.create_collection()
+    vi.index_chunks(chunks)
+    plain = SimpleSimilarityReranker(embedder=e, top_n=30)
+    fast = build_reranker('simple', top_n=30, embedder=e, vector_indexer=vi)
+    assert fast.vector_indexer is vi
+    q = 'aspirin dose for children'
+    results = vi.search(q, top_k=25) + [{'chunk_id': 'foreign', 'text': 'a text the collection never saw', 'score': 0.0}]
+    pairs = [(q, r['text']) for r in results]
+    assert vi.rows_of_texts([r['text'] for r in results])[-1] == -1
+    a, b = plain.score_pairs(pairs), fast.score_pairs(pairs)
+    assert np.allclose(a, b, atol=2e-6)
+    ra, rb = plain.rerank(q, copy.deepcopy(results), top_k=10), fast.rerank(q, copy.deepcopy(results), top_k=10)
+    assert [r['chunk_id'] for r in ra] == [r['chunk_id'] for r in rb]
+    # a collection of another metric or embedder is not used
+    other = VectorIndexer('d', e, use_in_memory=True, distance_metric='dot')
+    assert build_reranker('simple', embedder=e, vector_indexer=other).vector_indexer is None
+    with pytest.raises(ValueError):
+        SimpleSimilarityReranker(embedder=e, vector_indexer=other)
 
 
 def test_scripts_build_and_query_1k_chunks_bm25_only(backend, tmp_path, capsys):
