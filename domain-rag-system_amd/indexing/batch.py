@@ -18,6 +18,7 @@ equals the unsharded one.
 from dataclasses import dataclass
 from typing import Optional
 
+import contextlib
 import os
 
 import numpy as np
@@ -69,6 +70,8 @@ class BatchSearcher:
         # weights with split-precision GEMMs: the reference's precision, src/reranker/rerank.py:79-84)
         self.ce_tokens_per_batch, self.ce_token_bucket = int(ce_tokens_per_batch), int(ce_token_bucket)
         self.ce_sort_by_length = True
+        self.ce_streams = int(os.environ.get('RAG_CE_STREAMS', '1'))   # HIP streams the cross-encoder mini-batches alternate between
+        self._ce_stream_pool = []
         # sharded: each rank embeds a slice of the queries and the slices are all-gathered
         # (RAG_SPLIT_EMBED=0: every rank embeds all of them)
         self.split_embed = False
@@ -283,20 +286,39 @@ class BatchSearcher:
         cu_host = cu_all.cpu().numpy()                   # the one host copy of the stage
         budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
         cb = self.cross_encoder.bert
-        if (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
-                and cb.config.hidden_size == 384 and not getattr(cb, 'fused_linear', False)):
-            # every GEMM of the layers is one of the library's own kernels, which take any row count: the
-            # coarse token grid (there for hipBLASLt's per-shape solutions) would only add padding rows
+        own_gemms = (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
+                     and cb.word.weight.dtype == torch.bfloat16 and cb.config.hidden_size == 384
+                     and not getattr(cb, 'fused_linear', False))
+        mixed_gemms = cb.word.weight.dtype == torch.float32 and getattr(cb, 'split_gemm', False)
+        if own_gemms or mixed_gemms:
+            # every GEMM of the layers is one of the library's own kernels, which take any row count, or a
+            # 16-bit-in / fp32-out library GEMM, which the per-shape solution table does not cover: the coarse
+            # token grid (there for hipBLASLt's per-shape solutions) would only add padding rows
             bucket = min(bucket, 128)
         if os.environ.get('RAG_CE_TOKENS'):
             budget = int(os.environ['RAG_CE_TOKENS'])
-        p0 = 0
+        # Mini-batches are independent: with ce_streams > 1 (RAG_CE_STREAMS) they alternate between HIP streams.
+        # Measured on the 1M-row workload (fp32 forward: matrix-core-bound GEMMs next to HBM-bound kernels): 2-4
+        # streams are 0-4 % slower than one, the kernels of one mini-batch already fill the chip; off by default.
+        main = torch.cuda.current_stream() if dev.type == 'cuda' else None
+        n_streams = self.ce_streams if main is not None else 1
+        if n_streams > 1:
+            while len(self._ce_stream_pool) < n_streams:
+                self._ce_stream_pool.append(torch.cuda.Stream())
+            for st in self._ce_stream_pool[:n_streams]:
+                st.wait_stream(main)
+        p0 = i_batch = 0
         while p0 < n_mine:
             # as many whole pairs as fit the token budget (a single pair always fits: budget >> max_len)
             p1 = int(np.searchsorted(cu_host, cu_host[p0] + budget, side='right')) - 1
             p1 = min(max(p1, p0 + 1), n_mine)
             total = int(cu_host[p1] - cu_host[p0])
-            if total > 0:
+            side = self._ce_stream_pool[i_batch % n_streams] if n_streams > 1 else None
+            i_batch += 1
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if total <= 0:
+                    p0 = p1
+                    continue
                 lens = plen[p0:p1]
                 longest = int((cu_host[p0 + 1:p1 + 1] - cu_host[p0:p1]).max())
                 cu = (cu_all[p0:p1 + 1] - cu_all[p0]).to(torch.int32)
@@ -311,6 +333,9 @@ class BatchSearcher:
                     cu_live = torch.cat([cu[:-1][keep], cu[-1:]])
                     logits_mine[p0 + keep] = self.cross_encoder.forward_packed(ids, types, pos, cu_live, longest)
             p0 = p1
+        if n_streams > 1:
+            for st in self._ce_stream_pool[:n_streams]:
+                main.wait_stream(st)
 
     # ---- whole path ------------------------------------------------------------------
     def retrieve(self, embed_ids, embed_mask, qterms, qoff, n_terms):

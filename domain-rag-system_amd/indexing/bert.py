@@ -106,6 +106,8 @@ class BertEncoder(nn.Module):
         self.fused_split_tails = True   # with split_gemm: one kernel for the work between two GEMMs
         self.split_attention = True     # with split_gemm: attention as split-precision MFMA products (rag_enc_attention_split_dev)
         self.split_dtype = torch.bfloat16   # 16-bit type of the split halves: bfloat16 (16 bits between them) or float16 (22)
+        self.fused_split_out = True     # fp16 halves, hidden 384: output projection / second feed-forward product with
+        #                                 everything around them in one kernel (rag_enc_linear_ln_split_dev)
         self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
@@ -260,6 +262,15 @@ class BertEncoder(nn.Module):
             self._split_cache[id(module)] = w3
         return w3
 
+    def _weight_halves(self, module):
+        import rag_hip
+        key = ('halves', id(module))
+        w = self._split_cache.get(key)
+        if w is None:
+            w = rag_hip.split_weight_halves(module.weight.detach())
+            self._split_cache[key] = w
+        return w
+
     def _forward_packed_split(self, x, cu_seqlens, max_seq_len, first_token_only=False):
         """The fp32 layers with every GEMM as a split-bf16 product (see _linear_split) and the work between
         two GEMMs in one kernel each: bias + residual + LayerNorm + split of the result, bias + GELU + split.
@@ -275,6 +286,10 @@ class BertEncoder(nn.Module):
         last = len(self.layers) - 1
         head_dim = self.config.hidden_size // self.config.num_attention_heads
         mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)
+        c = self.config
+        fused_out = (self.fused_split_out
+                     and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, half)
+                     and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, half))
         for li, l in enumerate(self.layers):
             cls_only = first_token_only and li == last
             if mfma_attn:
@@ -288,7 +303,16 @@ class BertEncoder(nn.Module):
                     ctx = ctx[cu_seqlens[:-1].long()]
                 ctx3 = rag_hip.enc_split_bf16x3_dev(ctx, half)
             if cls_only:
-                x = x[cu_seqlens[:-1].long()]
+                x = x[cu_seqlens[:-1].long()].contiguous()
+            if fused_out:
+                # projection + bias + residual + LayerNorm + split in one kernel; then the first feed-forward product
+                # as a library GEMM, and bias + GELU + second product + bias + residual + LayerNorm + split in one
+                x, xs = rag_hip.enc_linear_ln_split_dev(ctx3, None, *self._weight_halves(l.attn_out), l.attn_out.bias, x,
+                                                        l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps)
+                x, xs = rag_hip.enc_linear_ln_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, *self._weight_halves(l.ffn_out),
+                                                        l.ffn_out.bias, x, l.ffn_norm.weight, l.ffn_norm.bias,
+                                                        l.ffn_norm.eps, want_split=li != last)
+                continue
             x, xs = rag_hip.enc_bias_add_layernorm_split_dev(mm(ctx3, l.attn_out), l.attn_out.bias, x,
                                                              l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps, half=half)
             hs = rag_hip.enc_bias_act_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, True, half)

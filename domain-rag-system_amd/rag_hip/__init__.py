@@ -90,6 +90,9 @@ SIGNATURES = {
     'rag_ce_pack_packed_dev': (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32,
                                       _i32, _vp, _vp, _vp, _vp]),
     'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
+    'rag_enc_linear_ln_split_dev': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'rag_enc_linear_ln_split_profile': (_i32, [_i32]),
+    'rag_enc_linear_ln_split_profile_read': (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
 }
 
 _lib = None
@@ -1020,3 +1023,61 @@ def enc_linear_dev(x, weight, bias, epilogue=EPILOGUE_BIAS, residual=None, gamma
                                    _ptr(residual, bf), _ptr(gamma, bf), _ptr(beta, bf), float(eps), DTYPE_BF16, _ptr(y),
                                    _stream()), 'rag_enc_linear_dev')
     return y
+
+
+def split_weight_halves(w):
+    """fp32 weight [N, K] -> (fp16(w), fp16(w - fp16(w))), each [N, K]: the weight operands of
+    rag_enc_linear_ln_split_dev."""
+    import torch
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def enc_linear_ln_split_supported(k, n, half):
+    import torch
+    return n == 384 and k % 32 == 0 and 32 <= k <= 2048 and half == torch.float16
+
+
+def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, want_split=True):
+    """LayerNorm(residual + a @ W.T + b2) * gamma + beta at fp32 precision on the fp16 matrix cores
+    (rag_enc_linear_ln_split_dev).  x_in fp32 [M, K] with b1: a = GELU(x_in + b1); x_in fp16 [M, 3K] (b1 None): a is
+    that split operand.  wh, wl: split_weight_halves(W), W [384, K].  Returns (y fp32 [M, 384], its fp16
+    [hi | hi | lo] split [M, 1152] or None)."""
+    import torch
+    m = x_in.shape[0]
+    n, k = wh.shape
+    is_split = x_in.dtype == torch.float16
+    if tuple(x_in.shape) != (m, 3 * k if is_split else k) or (not is_split and x_in.dtype != torch.float32):
+        raise ValueError("x_in must be fp32 [M, K] or fp16 [M, 3K]")
+    if not is_split and (b1 is None or tuple(b1.shape) != (k,)):
+        raise ValueError("an fp32 input needs its bias b1 [K]")
+    if tuple(wl.shape) != (n, k) or tuple(residual.shape) != (m, n):
+        raise ValueError("wl must have the shape of wh and residual must be [M, N]")
+    for v in (b2, gamma, beta):
+        if tuple(v.shape) != (n,):
+            raise ValueError("b2, gamma and beta must be [N]")
+    y = torch.empty((m, n), dtype=torch.float32, device=x_in.device)
+    ys = torch.empty((m, 3 * n), dtype=torch.float16, device=x_in.device) if want_split else None
+    f32 = torch.float32
+    check(lib().rag_enc_linear_ln_split_dev(_ptr(x_in), 1 if is_split else 0, None if is_split else _ptr(b1, f32),
+                                            _ptr(wh, torch.float16), _ptr(wl, torch.float16), _ptr(b2, f32),
+                                            _ptr(residual, f32), _ptr(gamma, f32), _ptr(beta, f32), float(eps), m, k, n,
+                                            _ptr(y), _ptr(ys) if ys is not None else None, _stream()),
+          'rag_enc_linear_ln_split_dev')
+    return y, ys
+
+
+def enc_linear_ln_split_profile(enable=True):
+    check(lib().rag_enc_linear_ln_split_profile(1 if enable else 0), 'rag_enc_linear_ln_split_profile')
+
+
+def enc_linear_ln_split_profile_read():
+    """(durations in ms, row counts, k) of the rag_enc_linear_ln_split_dev launches since the last read."""
+    ms = np.zeros(1024, np.float32)
+    rows = np.zeros(1024, np.int64)
+    ks = np.zeros(1024, np.int32)
+    n = _i32(0)
+    check(lib().rag_enc_linear_ln_split_profile_read(ms.ctypes.data, rows.ctypes.data, ks.ctypes.data, 1024, C.byref(n)),
+          'rag_enc_linear_ln_split_profile_read')
+    return ms[:n.value].copy(), rows[:n.value].copy(), ks[:n.value].copy()

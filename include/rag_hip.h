@@ -429,6 +429,27 @@ int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, 
                                          const float* d_gamma, const float* d_beta, float eps, int64_t rows,
                                          int32_t hidden, int32_t half_dtype, float* d_out, void* d_out_split,
                                          void* stream);
+/* Dense layer + residual + LayerNorm of a 384-wide BERT layer at float32 precision on the 16-bit matrix cores
+ * (the BertOutput and BertSelfOutput sub-layers of the float32 cross-encoder forward behind
+ * CrossEncoder.predict, reference src/reranker/rerank.py:79-84):
+ *   y[m] = LayerNorm(residual[m] + a[m] W^T + b2) * gamma + beta,      W [n = 384][k], y fp32 [m][384]
+ * where the left operand a is, with in_is_split == 0,  a = GELU(in + b1)  for in fp32 [m][k], the first
+ * product of the feed-forward block without its bias (erf GELU, evaluated to fp32 round-off), or, with
+ * in_is_split != 0, the operand given by in = fp16 [m][3k] rows [hi | hi | lo] (what rag_enc_split_bf16x3_dev
+ * and rag_enc_attention_split_dev write with RAG_DTYPE_F16; b1 is ignored).  W comes as its fp16 halves
+ * wh = fp16(W), wl = fp16(W - wh), each [384][k] row-major.  The product is hi.hi + lo.hi + hi.lo with fp32
+ * accumulation; bias, residual and LayerNorm are fp32.  d_y_split (may be NULL): fp16 [m][1152] rows
+ * [hi | hi | lo] of y, the operand of the next split-precision GEMM.  k a multiple of 32 up to 2048;
+ * outputs must not alias the input; residual may alias y.                                          */
+int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
+                                const void* d_wl, const float* d_b2, const float* d_residual,
+                                const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
+                                int32_t n, float* d_y, void* d_y_split, void* stream);
+/* Measurement aid (no counterpart in the reference): HIP event pairs around the launches of
+ * rag_enc_linear_ln_split_dev while enabled (up to 1024); the read returns durations in ms, row counts and k. */
+int rag_enc_linear_ln_split_profile(int32_t enable);
+int rag_enc_linear_ln_split_profile_read(float* out_ms, int64_t* out_rows, int32_t* out_k, int32_t max_n,
+                                         int32_t* out_n);
 /* BERT's input embedding: out[t] = LayerNorm(word[ids[t]] + position[pos[t]] +
  * type_emb[types[t]]) (types NULL = all 0), tables [vocab|max_pos|n_types][hidden];
  * ids outside a table are clamped and flagged (RAG_FAULT_TOKEN).                        */

@@ -170,3 +170,70 @@ def test_mlp_argument_errors():
         rag_hip.enc_mlp_dev(x, w1, b1[:32], w2, b2, gamma, beta)
     with pytest.raises(ValueError):
         rag_hip.enc_mlp_dev(x.float(), w1, b1, w2, b2, gamma, beta)
+
+
+@pytest.mark.parametrize('m,k', [(1000, 1536), (128, 384), (37, 64), (1, 32), (4099, 1536)])
+def test_linear_ln_split_matches_float64(m, k):
+    """rag_enc_linear_ln_split_dev, both operand sources, against float64:
+    LayerNorm(residual + GELU(h + b1) W^T + b2) from the fp32 first product, and
+    LayerNorm(residual + a W^T + b2) from a pre-split fp16 operand; plus the split written for the next GEMM."""
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(1000 + m + k)
+    h = torch.randn((m, k), generator=g, device=dev) * 1.2
+    b1 = torch.randn((k,), generator=g, device=dev) * 0.3
+    w = torch.randn((384, k), generator=g, device=dev) * 0.05
+    b2, gamma, beta = (torch.randn((384,), generator=g, device=dev) * s + o for s, o in ((0.2, 0), (0.3, 1.0), (0.2, 0)))
+    res = torch.randn((m, 384), generator=g, device=dev)
+    wh, wl = rag_hip.split_weight_halves(w)
+    assert wh.dtype == torch.float16 and float((wh.double() + wl.double() - w.double()).abs().max()) < 1e-7
+
+    def ref(a):
+        pre = res.double() + a @ w.double().t() + b2.double()
+        return torch.nn.functional.layer_norm(pre, (384,), gamma.double(), beta.double(), 1e-12)
+    y, ys = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12)
+    want = ref(torch.nn.functional.gelu(h.double() + b1.double()))
+    err = float((y.double() - want).abs().max())
+    # the same block in plain fp32 PyTorch ops, for scale: the kernel must be in the same round-off class
+    plain = torch.nn.functional.layer_norm(res + torch.nn.functional.gelu(h + b1) @ w.t() + b2, (384,), gamma, beta, 1e-12)
+    err_plain = float((plain.double() - want).abs().max())
+    print(f'm={m} k={k}: max error vs float64: kernel {err:.2e}, fp32 PyTorch ops {err_plain:.2e}')
+    assert err < max(3 * err_plain, 2e-6), (err, err_plain)
+    assert ys.dtype == torch.float16 and tuple(ys.shape) == (m, 1152) and torch.equal(ys[:, :384], ys[:, 384:768])
+    assert float((ys[:, :384].double() + ys[:, 768:].double() - y.double()).abs().max()) < 2e-6
+    assert torch.equal(ys[:, :384], y.to(torch.float16))
+    y2, none = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12, want_split=False)
+    assert none is None and torch.equal(y2, y)
+    # pre-split operand (what the attention kernel hands to the output projection)
+    a3 = rag_hip.enc_split_bf16x3_dev(h, torch.float16)
+    y3, _ = rag_hip.enc_linear_ln_split_dev(a3, None, wh, wl, b2, res, gamma, beta, 1e-12)
+    err3 = float((y3.double() - ref(h.double())).abs().max())
+    assert err3 < max(3 * err_plain, 2e-6), (err3, err_plain)
+    # the separate route it replaces: library GEMM on [hi|hi|lo] operands + bias/residual/LayerNorm kernel
+    w3 = rag_hip.split_weight_bf16x3(w, torch.float16)
+    sep, _ = rag_hip.enc_bias_add_layernorm_split_dev(torch.mm(a3, w3.t(), out_dtype=torch.float32), b2, res, gamma, beta,
+                                                      1e-12, half=torch.float16)
+    assert float((sep - y3).abs().max()) < max(3 * err_plain, 2e-6)
+    with pytest.raises(ValueError):
+        rag_hip.enc_linear_ln_split_dev(h, None, wh, wl, b2, res, gamma, beta, 1e-12)
+
+
+def test_cross_encoder_fp32_forward_same_with_and_without_the_fused_output_kernels():
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    m, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                split_dtype=torch.float16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    lens = torch.randint(5, 150, (300,), generator=g, device=dev, dtype=torch.int32)
+    cu = torch.zeros((301,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    t = int(cu[-1])
+    ids = torch.randint(1000, cfg.vocab_size, (t,), generator=g, device=dev, dtype=torch.int32)
+    types = torch.zeros_like(ids)
+    pos = torch.cat([torch.arange(int(n), dtype=torch.int32, device=dev) for n in lens])
+    with torch.no_grad():
+        assert m.bert.fused_split_out
+        a = m.forward_packed(ids, types, pos, cu, int(lens.max()))
+        m.bert.fused_split_out = False
+        b = m.forward_packed(ids, types, pos, cu, int(lens.max()))
+    assert float((a - b).abs().max()) < 1e-6
