@@ -326,6 +326,7 @@ def main():
     barrier()
     dense.profile(True)
     rag_hip.enc_mlp_profile(True)
+    rag_hip.enc_linear_ln_split_profile(True)
     t0 = time.perf_counter()
     out = run(queries[args.warmup:args.warmup + args.steps])[-1]
     barrier()
@@ -334,6 +335,8 @@ def main():
     dense.profile(False)
     mlp_ms, mlp_rows = rag_hip.enc_mlp_profile_read()
     rag_hip.enc_mlp_profile(False)
+    lls_ms, lls_rows, lls_k = rag_hip.enc_linear_ln_split_profile_read()
+    rag_hip.enc_linear_ln_split_profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -403,6 +406,46 @@ def main():
             roofline_ff['traffic'] = round(per_row * float(mlp_rows.mean()) / 1e9, 2)
             roofline_ff['traffic_unit'] = 'GB per launch (bytes per row from rocprofv3 --pmc passes of scripts/mlp_bench.py)'
 
+    # float32 cross-encoder: the hand-written kernel with the largest share of a step is ffn_out_split_kernel
+    # in its feed-forward form (K = intermediate size): LayerNorm(residual + GELU(h + b1) W2^T + b2) with its
+    # split output.  Algorithmic work of a launch over `rows` tokens: 2 * rows * K * hidden FLOPs (the kernel
+    # executes three fp16 MFMA products per algorithmic one: priced against the fp16 matrix peak, executed rate
+    # beside it) and rows * (4 K + 4 hidden [residual] + 4 hidden [y] + 6 hidden [y as fp16 hi | hi | lo]) bytes.
+    if roofline_ff is None and len(lls_ms):
+        hid, inter = ce_cfg.hidden_size, ce_cfg.intermediate_size
+        sel = lls_k == inter
+        if sel.any():
+            f_rows, f_s = float(lls_rows[sel].sum()), float(lls_ms[sel].sum()) / 1e3
+            f_flops = 2.0 * f_rows * inter * hid
+            f_bytes = f_rows * (4.0 * inter + 14.0 * hid)
+            roofline_ff = {'kernel': 'ffn_out_split_kernel<0> (second feed-forward product + bias + GELU + residual + LayerNorm + split, '
+                                     'fp32-equivalent on fp16 MFMA)',
+                           'bound': 'mfma', 'achieved': round(f_flops / f_s / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': round(f_flops / f_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                           'executed_tflops': round(3 * f_flops / f_s / 1e12, 1),
+                           'executed_frac': round(3 * f_flops / f_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                           'vs_fp32_matrix_peak': round(f_flops / f_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
+                           'launches_per_step': int(sel.sum()) // max(args.steps, 1),
+                           'avg_launch_ms': round(f_s * 1e3 / int(sel.sum()), 3),
+                           'avg_launch_rows': int(f_rows / int(sel.sum())),
+                           'ms_per_step': round(f_s * 1e3 / max(args.steps, 1), 2),
+                           'algorithmic_gbs': round(f_bytes / f_s / 1e9, 1),
+                           'hbm_frac': round(f_bytes / f_s / 1e9 / HBM_PEAK_GBS, 4)}
+            if (~sel).any():      # the same kernel as attention-output projection (K = hidden, operand already split)
+                o_rows, o_s = float(lls_rows[~sel].sum()), float(lls_ms[~sel].sum()) / 1e3
+                roofline_ff['attention_output_form'] = {
+                    'ms_per_step': round(o_s * 1e3 / max(args.steps, 1), 2),
+                    'algorithmic_gbs': round(o_rows * 18.0 * hid / o_s / 1e9, 1),
+                    'hbm_frac': round(o_rows * 18.0 * hid / o_s / 1e9 / HBM_PEAK_GBS, 4),
+                    'executed_tflops': round(6.0 * o_rows * hid * hid / o_s / 1e12, 1)}
+            ff_pmc = os.path.join(ROOT, 'profiles', 'pmc_linear_ln_split.json')
+            if os.path.exists(ff_pmc):
+                with open(ff_pmc) as f:
+                    per_row = float(json.load(f)['traffic_bytes_per_row'])
+                roofline_ff['traffic'] = round(per_row * f_rows / int(sel.sum()) / 1e9, 2)
+                roofline_ff['traffic_unit'] = ('GB per launch (bytes per row from rocprofv3 --pmc passes of '
+                                               'scripts/split_out_bench.py, times the rows of an average launch)')
+
     result = {
         'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
         'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
@@ -425,7 +468,7 @@ def main():
                    'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU',
                    'batch_pipelining': bool(world == 1 and args.pipeline and args.steps > 1)},
         'stage_ms_per_step': stage_ms,
-        # `roofline`: the kernel with the largest share of a step (the feed-forward block); the dense scan beside it
+        # `roofline`: the hand-written kernel with the largest share of a step (the feed-forward block); the dense scan beside it
         'roofline': roofline_ff if roofline_ff is not None else roofline,
         'roofline_dense_scan': roofline,
     }

@@ -65,8 +65,8 @@ struct FfnOutParams {
     const float* h;        // SRC 0: [M][K] fp32, the first product without its bias
     const f16* hs;         // SRC 1: [M][3K] fp16, a finished operand already split as [hi | hi | lo]
     const float* b1;       // SRC 0: [K] bias added before the activation
-    const f16* wh;         // [384][K] high halves of W
-    const f16* wl;         // [384][K] low halves
+    const f16* wh;         // high halves of W [384][K], packed by chunk (pack_weights_kernel)
+    const f16* wl;         // low halves, packed the same way
     const float* b2;       // [384]
     const float* residual; // [M][384]
     const float* gamma;    // [384]
@@ -160,19 +160,15 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
     const int last = n_chunks - 1;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
-    // ---- weight staging.  Image row f holds the chunk's 32 k-columns of feature (f with bits 2 and 3 swapped),
-    // piece j (16 bytes = 8 columns) at j ^ ((f >> 2) & 3): with that row order registers 8t..8t+7 of accumulator
-    // tile m are features 32m + 16t + 8h + 0..7 of the lane's token.
-    uint32_t off2[FS_W_DMAS];
-#pragma unroll
-    for (int i = 0; i < FS_W_DMAS; ++i) {
-        const int L = 64 * (wave + 4 * i) + lane;
-        const int f = L / 4, j2 = (L % 4) ^ ((f >> 2) & 3);
-        const int fo = (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1);
-        off2[i] = (uint32_t)((fo * p.K + j2 * 8) * 2);
-    }
+    // ---- weight staging.  The weights arrive packed (pack_weights_kernel below): chunk c of an image is 24 KiB of
+    // contiguous memory already in LDS order, so a direct-to-LDS load moves 1 KiB of whole lines.  Image row f
+    // holds the chunk's 32 k-columns of feature (f with bits 2 and 3 swapped), piece j (16 bytes = 8 columns) at
+    // j ^ ((f >> 2) & 3): with that row order registers 8t..8t+7 of accumulator tile m are features
+    // 32m + 16t + 8h + 0..7 of the lane's token.
     auto dma_w = [&](int c, int buf, int i, int lo) {         // piece group i of chunk c, one image -> buffer buf
-        lds_dma16(lds0 + (buf * 2 + lo) * FS_W_BYTES + 1024 * (wave + 4 * i), (lo ? p.wl : p.wh) + c * FS_C, off2[i]);
+        lds_dma16(lds0 + (buf * 2 + lo) * FS_W_BYTES + 1024 * (wave + 4 * i),
+                  reinterpret_cast<const unsigned char*>(lo ? p.wl : p.wh) + (size_t)c * FS_W_BYTES + 1024 * (wave + 4 * i),
+                  (uint32_t)(16 * lane));
     };
 
     // ---- operand staging: a wave's 32 tokens x 32 k-columns of a chunk (4 KiB either way) come through LDS too,
@@ -524,6 +520,28 @@ extern "C" int rag_enc_linear_ln_split_debug(unsigned long long* out8) {
 namespace {
 #endif
 
+// W [384][K] fp32 -> the two packed fp16 images the kernel streams: piece P = 1536 c + 4 f + j of an image (16
+// bytes) holds columns 32 c + 8 (j ^ ((f >> 2) & 3)) + 0..7 of feature (f with bits 2 and 3 swapped).
+__global__ void pack_weights_kernel(const float* __restrict__ w, int K, f16x8* __restrict__ wh, f16x8* __restrict__ wl) {
+    const int n_pieces = (K / FS_C) * (FS_HID * 4);
+    for (int P = blockIdx.x * blockDim.x + threadIdx.x; P < n_pieces; P += gridDim.x * blockDim.x) {
+        const int c = P / (FS_HID * 4), L = P % (FS_HID * 4);
+        const int f = L / 4, j = (L % 4) ^ ((f >> 2) & 3);
+        const int fo = (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1);
+        const float* src = w + (size_t)fo * K + FS_C * c + 8 * j;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f16 a, b;
+            split_f16(src[e], a, b);
+            hi[e] = a;
+            lo[e] = b;
+        }
+        wh[P] = hi;
+        wl[P] = lo;
+    }
+}
+
 bool aligned16(std::initializer_list<const void*> ptrs) {
     for (const void* q : ptrs)
         if (reinterpret_cast<uintptr_t>(q) % 16 != 0) return false;
@@ -580,6 +598,19 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
         g_fs_prof.rows[g_fs_prof.n] = m;
         g_fs_prof.k[g_fs_prof.n++] = k;
     }
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_linear_ln_split_pack_dev(const float* d_w, int32_t k, int32_t n, void* d_wh, void* d_wl, void* stream_) {
+    RAG_REQUIRE(n == FS_HID, RAG_ELIMIT, "rag_enc_linear_ln_split_pack: the output width must be %d (got %d)", FS_HID, n);
+    RAG_REQUIRE(k >= FS_C && k % FS_C == 0 && k <= FS_MAX_K, RAG_ELIMIT,
+                "rag_enc_linear_ln_split_pack: the input width must be a multiple of %d up to %d (got %d)", FS_C, FS_MAX_K, k);
+    RAG_REQUIRE(d_w && d_wh && d_wl, RAG_EINVAL, "rag_enc_linear_ln_split_pack: null pointer");
+    RAG_REQUIRE(aligned16({d_w, d_wh, d_wl}), RAG_EINVAL, "rag_enc_linear_ln_split_pack: pointers must be 16-byte aligned");
+    const int n_pieces = (k / FS_C) * (FS_HID * 4);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((n_pieces + 255) / 256), dim3(256), 0, (hipStream_t)stream_, d_w, (int)k,
+                       (f16x8*)d_wh, (f16x8*)d_wl);
+    RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 

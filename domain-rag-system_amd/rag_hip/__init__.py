@@ -91,6 +91,7 @@ SIGNATURES = {
                                       _i32, _vp, _vp, _vp, _vp]),
     'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
     'rag_enc_linear_ln_split_dev': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'rag_enc_linear_ln_split_pack_dev': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
     'rag_enc_linear_ln_split_profile': (_i32, [_i32]),
     'rag_enc_linear_ln_split_profile_read': (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
 }
@@ -1026,12 +1027,32 @@ def enc_linear_dev(x, weight, bias, epilogue=EPILOGUE_BIAS, residual=None, gamma
 
 
 def split_weight_halves(w):
-    """fp32 weight [N, K] -> (fp16(w), fp16(w - fp16(w))), each [N, K]: the weight operands of
-    rag_enc_linear_ln_split_dev."""
+    """fp32 weight [384, K] on the GPU -> the weight operands of rag_enc_linear_ln_split_dev: the fp16 halves
+    (hi = fp16(w), lo = fp16(w - hi)), each packed by 32-column chunk in the order the kernel streams them
+    (rag_enc_linear_ln_split_pack_dev).  The tensors keep the shape [384, K] but not that layout:
+    unpack_weight_halves gives the plain matrices back."""
     import torch
-    hi = w.to(torch.float16)
-    lo = (w - hi.float()).to(torch.float16)
-    return hi.contiguous(), lo.contiguous()
+    n, k = w.shape
+    w = w.contiguous().float()
+    wh = torch.empty((n, k), dtype=torch.float16, device=w.device)
+    wl = torch.empty((n, k), dtype=torch.float16, device=w.device)
+    check(lib().rag_enc_linear_ln_split_pack_dev(_ptr(w, torch.float32), k, n, _ptr(wh), _ptr(wl), _stream()),
+          'rag_enc_linear_ln_split_pack_dev')
+    return wh, wl
+
+
+def unpack_weight_halves(packed):
+    """A packed image of split_weight_halves -> the plain [384, K] matrix (tests, inspection)."""
+    import torch
+    n, k = packed.shape
+    f = torch.arange(n, device=packed.device)
+    fo = (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1)
+    pos = torch.arange(4, device=packed.device)
+    j = pos[None, :] ^ ((f[:, None] >> 2) & 3)                      # image row f, position pos holds piece j
+    img = packed.reshape(k // 32, n, 4, 8)
+    out = torch.empty((k // 32, n, 4, 8), dtype=packed.dtype, device=packed.device)
+    out[:, fo[:, None].expand(n, 4), j] = img[:, f[:, None].expand(n, 4), pos[None, :].expand(n, 4)]
+    return out.permute(1, 0, 2, 3).reshape(n, k).contiguous()
 
 
 def enc_linear_ln_split_supported(k, n, half):

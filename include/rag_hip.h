@@ -437,7 +437,8 @@ int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, 
  * product of the feed-forward block without its bias (erf GELU, evaluated to fp32 round-off), or, with
  * in_is_split != 0, the operand given by in = fp16 [m][3k] rows [hi | hi | lo] (what rag_enc_split_bf16x3_dev
  * and rag_enc_attention_split_dev write with RAG_DTYPE_F16; b1 is ignored).  W comes as its fp16 halves
- * wh = fp16(W), wl = fp16(W - wh), each [384][k] row-major.  The product is hi.hi + lo.hi + hi.lo with fp32
+ * wh = fp16(W), wl = fp16(W - wh), each 384 * k elements packed by rag_enc_linear_ln_split_pack_dev (once per
+ * weight: the kernel streams them chunk by chunk).  The product is hi.hi + lo.hi + hi.lo with fp32
  * accumulation; bias, residual and LayerNorm are fp32.  d_y_split (may be NULL): fp16 [m][1152] rows
  * [hi | hi | lo] of y, the operand of the next split-precision GEMM.  k a multiple of 32 up to 2048;
  * outputs must not alias the input; residual may alias y.                                          */
@@ -445,6 +446,11 @@ int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const flo
                                 const void* d_wl, const float* d_b2, const float* d_residual,
                                 const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
                                 int32_t n, float* d_y, void* d_y_split, void* stream);
+/* The weight operands of rag_enc_linear_ln_split_dev from W fp32 [n = 384][k] row-major (a Linear layer's weight as
+ * transformers stores it): d_wh, d_wl each 384 * k fp16, where 16-byte piece 1536 c + 4 f + j holds columns
+ * 32 c + 8 (j ^ ((f >> 2) & 3)) + 0..7 of row (f with bits 2 and 3 swapped): every 32-column chunk contiguous
+ * and in the order of the kernel's LDS image.                                                        */
+int rag_enc_linear_ln_split_pack_dev(const float* d_w, int32_t k, int32_t n, void* d_wh, void* d_wl, void* stream);
 /* Measurement aid (no counterpart in the reference): HIP event pairs around the launches of
  * rag_enc_linear_ln_split_dev while enabled (up to 1024); the read returns durations in ms, row counts and k. */
 int rag_enc_linear_ln_split_profile(int32_t enable);

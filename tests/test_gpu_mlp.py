@@ -186,7 +186,10 @@ def test_linear_ln_split_matches_float64(m, k):
     b2, gamma, beta = (torch.randn((384,), generator=g, device=dev) * s + o for s, o in ((0.2, 0), (0.3, 1.0), (0.2, 0)))
     res = torch.randn((m, 384), generator=g, device=dev)
     wh, wl = rag_hip.split_weight_halves(w)
-    assert wh.dtype == torch.float16 and float((wh.double() + wl.double() - w.double()).abs().max()) < 1e-7
+    # the packed images hold exactly fp16(w) and fp16(w - fp16(w))
+    hi = w.to(torch.float16)
+    assert wh.dtype == torch.float16 and torch.equal(rag_hip.unpack_weight_halves(wh), hi)
+    assert torch.equal(rag_hip.unpack_weight_halves(wl), (w - hi.float()).to(torch.float16))
 
     def ref(a):
         pre = res.double() + a @ w.double().t() + b2.double()
