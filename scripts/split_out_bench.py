@@ -22,7 +22,8 @@ def main():
     ap.add_argument('--k', type=int, default=1536, help='input width: 1536 = second feed-forward product, 384 = output projection')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--abl', default=None, help='comma list of RAG_FS_ABL masks to time (library built with -DFS_STAMPS=1)')
-    ap.add_argument('--only', default=None, choices=['fused'], help='run only the fused kernel (profiler passes)')
+    ap.add_argument('--only', default=None, choices=['fused', 'fused-split'],
+                    help='run only the fused kernel, fp32 input or pre-split input (profiler passes)')
     args = ap.parse_args()
     import rag_hip
     dev = torch.device('cuda:0')
@@ -56,7 +57,21 @@ def main():
         buf = (ctypes.c_ulonglong * 8)()
         rag_hip.load_library().rag_enc_linear_ln_split_debug(buf)
         return 'prologue %d, loop %d (%d per chunk), epilogue %d' % (buf[0], buf[1], buf[1] // max(buf[3], 1), buf[2])
+    def check():
+        """max error of both operand forms against float64 on the first 2048 + last 100 tokens"""
+        sel = torch.cat([torch.arange(0, min(m, 2048), device=dev), torch.arange(max(m - 100, 0), m, device=dev)])
+        y0, ys0 = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12)
+        a3_ = rag_hip.enc_split_bf16x3_dev(h, torch.float16)
+        y1, _ = rag_hip.enc_linear_ln_split_dev(a3_, None, wh, wl, b2, res, gamma, beta, 1e-12)
+        hd, wd = h[sel].double(), w.double()
+        ref = lambda a: torch.nn.functional.layer_norm(res[sel].double() + a @ wd.t() + b2.double(), (384,), gamma.double(), beta.double(), 1e-12)
+        e0 = float((y0[sel].double() - ref(torch.nn.functional.gelu(hd + b1.double()))).abs().max())
+        e1 = float((y1[sel].double() - ref(hd)).abs().max())
+        n = 384
+        es = float(((ys0[sel, :n].double() + ys0[sel, 2 * n:].double()) - y0[sel].double()).abs().max())
+        return f'max error vs float64: fp32-in {e0:.2e}, split-in {e1:.2e}; split output hi + lo - y: {es:.2e}'
     if args.abl:
+        print(check(), flush=True)
         a3 = rag_hip.enc_split_bf16x3_dev(h, torch.float16)
         with torch.no_grad():
             for mask in args.abl.split(','):
@@ -65,6 +80,12 @@ def main():
                 s0 = stamps()
                 ms1 = timed(lambda: rag_hip.enc_linear_ln_split_dev(a3, None, wh, wl, b2, res, gamma, beta, 1e-12))
                 print(f'abl {mask:>3}: fp32-in {ms0:.3f} ms [{s0}]   split-in {ms1:.3f} ms [{stamps()}]', flush=True)
+        return
+    if args.only == 'fused-split':
+        a3 = rag_hip.enc_split_bf16x3_dev(h, torch.float16)
+        with torch.no_grad():
+            ms = timed(lambda: rag_hip.enc_linear_ln_split_dev(a3, None, wh, wl, b2, res, gamma, beta, 1e-12))
+        print(f'fused (pre-split in): tokens={m} k={k} {ms:.3f} ms  {3 * flops / ms / 1e9:.0f} TFLOP/s executed', flush=True)
         return
     with torch.no_grad():
         ms = timed(lambda: rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12))
