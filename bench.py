@@ -71,8 +71,6 @@ def parse():
                     help='tuning aid: q|k|v and output projections as library GEMMs instead of rag_enc_linear384_dev')
     ap.add_argument('--ce-library-mlp', action='store_true',
                     help='tuning aid: feed-forward blocks as library GEMMs + tail kernels instead of rag_enc_mlp_dev')
-    ap.add_argument('--ce-fused-linear', action='store_true',
-                    help='cross-encoder output projection + residual + LayerNorm as one librag_hip GEMM')
     ap.add_argument('--ce-torch-ops', action='store_true',
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
@@ -285,7 +283,6 @@ def main():
                                       split_gemm=True, split_dtype=torch.float16)
         else:
             m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32)
-        m.bert.fused_linear = bool(args.ce_fused_linear)
         m.bert.fused_mlp = not args.ce_library_mlp
         m.bert.native_linear = not args.ce_library_linear
         m.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
@@ -301,6 +298,8 @@ def main():
     searcher = make_searcher(ce, args.rerank_top_n)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
+    # work buffers of the two indexes sized once, before anything is timed: no search of the run allocates
+    searcher.reserve(args.batch, max(int(q['n_terms']) for q in queries))
     if args.tune_gemms and searcher.ce_packed:
         gemm_tuning.tune_cross_encoder(ce, searcher.ce_tokens_per_batch, searcher.ce_token_bucket)
 

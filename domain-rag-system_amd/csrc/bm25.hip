@@ -432,6 +432,20 @@ extern "C" int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const 
     return bm25_search_on(h, w, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count, stream);
 }
 
+extern "C" int rag_bm25_reserve(rag_bm25_t h, int32_t max_queries, int32_t max_terms_total, int32_t max_k) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_bm25_reserve: null handle");
+    RAG_REQUIRE(max_queries >= 1 && max_terms_total >= 0 && max_k >= 1 && max_k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_bm25_reserve: need max_queries >= 1, max_terms_total >= 0 and 1 <= max_k <= %d", RAG_MAX_K);
+    if (h->n_docs == 0) return RAG_OK;
+    const Bm25WorkBytes need = bm25_work_bytes(h, max_queries, max_terms_total, max_k);
+    int rc;
+    if ((rc = h->toff.ensure(need.toff))) return rc;
+    if ((rc = h->tau.ensure(need.tau))) return rc;
+    if ((rc = h->cand_key.ensure(need.cand_key))) return rc;
+    if ((rc = h->cand_row.ensure(need.cand_row))) return rc;
+    return h->cand_count.ensure(need.cand_count);
+}
+
 // ---- the same search for callers that cannot allocate -----------------------------------------------
 // The work buffers live in a file-scope device array instead of the handle's grow-only buffers: nothing in
 // this entry point calls hipMalloc / hipFree or any routine that does.  Each GPU the library runs on holds

@@ -624,8 +624,10 @@ extern "C" int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_
 
 namespace {
 
+// Geometry of a scan (query blocks, row strips) for p.n_queries / p.n_rows / p.k / p.cap, and the handle's work
+// buffers grown to hold it.  No launch: rag_dense_reserve runs this alone.
 template <int WQ, int TQ, int WR, int TR>
-int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool preset_tau = false) {
+int plan_scan(rag_dense_t h, DenseScanParams& p) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
     p.n_qblocks = (p.n_queries + Cfg::BQ - 1) / Cfg::BQ;
     // one resident wave of workgroups (LDS decides how many fit a CU), strips a multiple of 8
@@ -646,8 +648,34 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool pres
     if (rc) return rc;
     rc = h->cand_count.ensure((size_t)p.n_queries * p.n_strips * sizeof(int32_t));
     if (rc) return rc;
-    rc = h->tau_shared.ensure((size_t)p.n_queries * sizeof(uint32_t));
+    return h->tau_shared.ensure((size_t)p.n_queries * sizeof(uint32_t));
+}
+
+// which tile configuration a batch of n_queries runs
+template <typename F>
+int dense_dispatch(int n_queries, F&& f) {
+    if (n_queries <= 32) return f(std::integral_constant<int, 0>{});
+    if (n_queries <= 64) return f(std::integral_constant<int, 1>{});
+    if (getenv("RAG_DENSE_WIDE") || n_queries < 256) return f(std::integral_constant<int, 2>{});
+    return f(std::integral_constant<int, 3>{});
+}
+
+int dense_cap(int k) {
+    int cap = 2 * k + BN;
+    if (cap < 3 * BN) cap = 3 * BN;
+    if (const char* e = getenv("RAG_DENSE_CAP")) {      // tuning aid: candidate list capacity
+        int v = atoi(e);
+        if (v >= k + BN && v <= 8192) cap = v;
+    }
+    return (cap + 63) / 64 * 64;
+}
+
+template <int WQ, int TQ, int WR, int TR>
+int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool preset_tau = false) {
+    using Cfg = DenseCfg<WQ, TQ, WR, TR>;
+    int rc = plan_scan<WQ, TQ, WR, TR>(h, p);
     if (rc) return rc;
+    const int64_t n_blocks = (int64_t)p.n_strips * p.n_qblocks;
     p.tau_shared = (uint32_t*)h->tau_shared.p;
     // key of -inf: below every real score
     if (!preset_tau)
@@ -692,13 +720,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     p.dim = h->dim;
     p.n_queries = n_queries;
     p.k = k;
-    int cap = 2 * k + BN;
-    if (cap < 3 * BN) cap = 3 * BN;
-    if (const char* e = getenv("RAG_DENSE_CAP")) {      // tuning aid: candidate list capacity
-        int v = atoi(e);
-        if (v >= k + BN && v <= 8192) cap = v;
-    }
-    p.cap = (cap + 63) / 64 * 64;
+    p.cap = dense_cap(k);
     p.euclid = h->metric == RAG_METRIC_EUCLID;
     p.split = 0;
     if (h->rows_split && !getenv("RAG_DENSE_NO_SPLIT")) {
@@ -717,10 +739,13 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
     int rc;
     auto scan = [&](DenseScanParams& pp, bool preset) -> int {
-        if (n_queries <= 32) return launch_scan<1, 1, 4, 1>(h, pp, stream, preset);
-        if (n_queries <= 64) return launch_scan<1, 2, 4, 1>(h, pp, stream, preset);
-        if (getenv("RAG_DENSE_WIDE") || n_queries < 256) return launch_scan<2, 2, 2, 2>(h, pp, stream, preset);
-        return launch_scan<4, 2, 2, 2>(h, pp, stream, preset);
+        return dense_dispatch(n_queries, [&](auto cfg) -> int {
+            constexpr int C = decltype(cfg)::value;
+            if constexpr (C == 0) return launch_scan<1, 1, 4, 1>(h, pp, stream, preset);
+            else if constexpr (C == 1) return launch_scan<1, 2, 4, 1>(h, pp, stream, preset);
+            else if constexpr (C == 2) return launch_scan<2, 2, 2, 2>(h, pp, stream, preset);
+            else return launch_scan<4, 2, 2, 2>(h, pp, stream, preset);
+        });
     };
     // Large batches over large shards: a pre-pass over the first rows (about 1.6 % of the scan)
     // gives every query a threshold before the main pass starts, so the main pass appends and
@@ -780,6 +805,37 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         RAG_HIP_TRY(hipGetLastError());
     }
     return RAG_OK;
+}
+
+extern "C" int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max_k) {
+    RAG_REQUIRE(h != nullptr, RAG_EINVAL, "rag_dense_reserve: null handle");
+    RAG_REQUIRE(max_queries >= 1 && max_k >= 1 && max_k <= RAG_MAX_K, RAG_ELIMIT,
+                "rag_dense_reserve: need max_queries >= 1 and 1 <= max_k <= %d (got %d, %d)", RAG_MAX_K, max_queries, max_k);
+    if (h->n_rows == 0) return RAG_OK;
+    // every tile configuration a batch of up to max_queries can run (the work buffers are sized by the configuration)
+    const int sizes[] = {1, 32, 64, 255, max_queries};
+    for (int nq : sizes) {
+        if (nq > max_queries) continue;
+        DenseScanParams p = {};
+        p.n_rows = h->n_rows;
+        p.n_queries = nq;
+        p.k = max_k;
+        p.cap = dense_cap(max_k);
+        int rc = dense_dispatch(nq, [&](auto cfg) -> int {
+            constexpr int C = decltype(cfg)::value;
+            if constexpr (C == 0) return plan_scan<1, 1, 4, 1>(h, p);
+            else if constexpr (C == 1) return plan_scan<1, 2, 4, 1>(h, p);
+            else if constexpr (C == 2) return plan_scan<2, 2, 2, 2>(h, p);
+            else return plan_scan<4, 2, 2, 2>(h, p);
+        });
+        if (rc) return rc;
+    }
+    int rc;
+    if (h->rows_split && (rc = h->queries_split.ensure((size_t)max_queries * h->dim * sizeof(float)))) return rc;
+    const size_t nk = (size_t)max_queries * max_k;
+    if ((rc = h->tmp_score.ensure(nk * sizeof(float)))) return rc;
+    if ((rc = h->tmp_row.ensure(nk * sizeof(int64_t)))) return rc;
+    return h->tmp_count.ensure((size_t)max_queries * sizeof(int32_t));
 }
 
 extern "C" int rag_dense_search(rag_dense_t h, const float* queries, int32_t n_queries, int32_t k,

@@ -287,8 +287,7 @@ class BatchSearcher:
         budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
         cb = self.cross_encoder.bert
         own_gemms = (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
-                     and cb.word.weight.dtype == torch.bfloat16 and cb.config.hidden_size == 384
-                     and not getattr(cb, 'fused_linear', False))
+                     and cb.word.weight.dtype == torch.bfloat16 and cb.config.hidden_size == 384)
         mixed_gemms = cb.word.weight.dtype == torch.float32 and getattr(cb, 'split_gemm', False)
         if own_gemms or mixed_gemms:
             # every GEMM of the layers is one of the library's own kernels, which take any row count, or a
@@ -336,6 +335,15 @@ class BatchSearcher:
         if n_streams > 1:
             for st in self._ce_stream_pool[:n_streams]:
                 main.wait_stream(st)
+
+    def reserve(self, max_batch: int, max_terms_total: int):
+        """Size the indexes' work buffers for batches of up to max_batch queries (max_terms_total BM25 query tokens in
+        all) at this searcher's list length, so that the searches of the path never allocate afterwards."""
+        k_list = min(2 * self.fetch_k, rag_hip.MAX_K)
+        if self.dense is not None:
+            self.dense.reserve(max_batch, k_list)
+        if self.bm25 is not None:
+            self.bm25.reserve(max_batch, max_terms_total, k_list)
 
     # ---- whole path ------------------------------------------------------------------
     def retrieve(self, embed_ids, embed_mask, qterms, qoff, n_terms):

@@ -108,7 +108,6 @@ class BertEncoder(nn.Module):
         self.split_dtype = torch.bfloat16   # 16-bit type of the split halves: bfloat16 (16 bits between them) or float16 (22)
         self.fused_split_out = True     # fp16 halves, hidden 384: output projection / second feed-forward product with
         #                                 everything around them in one kernel (rag_enc_linear_ln_split_dev)
-        self.fused_linear = False    # bfloat16, hidden 384: output projection through rag_enc_linear_dev
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
         self.fused_attn_norm = False # ... with the residual + LayerNorm after the output projection in the same kernel
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
@@ -194,13 +193,7 @@ class BertEncoder(nn.Module):
                                              l.attn_norm.bias, l.ffn_in.weight, l.ffn_in.bias, l.ffn_out.weight,
                                              l.ffn_out.bias, l.ffn_norm.weight, l.ffn_norm.bias, l.ffn_norm.eps)
                 continue
-            if self.fused_linear and rag_hip.enc_linear_supported(ctx, l.attn_out.weight) and x.shape[1] == 384:
-                # output projection with bias + residual + LayerNorm in the GEMM epilogue
-                x = rag_hip.enc_linear_dev(ctx, l.attn_out.weight, l.attn_out.bias,
-                                           rag_hip.EPILOGUE_BIAS_RESIDUAL_LAYERNORM, x, l.attn_norm.weight,
-                                           l.attn_norm.bias, l.attn_norm.eps)
-            else:
-                x = self._attn_output(l, ctx, x, lin)
+            x = self._attn_output(l, ctx, x, lin)
             x = self._feed_forward(l, x, lin)
         return x
 

@@ -196,7 +196,9 @@ class BM25Indexer:
         self.normalizer = medical_normalizer or MedicalTermNormalizer()
         self.bm25 = None                    # Bm25Arrays once built (name kept for callers)
         self.chunks = []
-        self.tokenized_corpus = []
+        self._tokenized_corpus = []
+        self._doc_tokens = None
+        self._words = []
         self._device_index = None
         self._short_keys = None
 
@@ -220,31 +222,57 @@ class BM25Indexer:
 
     def index_chunks(self, chunks):
         """Tokenise every chunk and build the device index.  Rebuilds from scratch on every
-        call (the reference appends to its token lists and corrupts a second build)."""
+        call (the reference appends to its token lists and corrupts a second build).  Tokenizer and
+        vocabulary run natively (rag_bm25_tokenize_*): ASCII texts are tokenised there, any other text by
+        `tokenize` here (Unicode word classes and case folding are Python's) and handed over as tokens."""
         self.chunks = chunks
-        self.tokenized_corpus = [self.tokenize(self._text_of(c)) for c in chunks]
-        self._build(self.tokenized_corpus)
+        docs, flags = [], np.zeros(len(chunks), np.uint8)
+        for d, c in enumerate(chunks):
+            text = self._text_of(c)
+            if text.isascii():
+                docs.append(text.encode('ascii'))
+            else:
+                docs.append('\n'.join(self.tokenize(text)).encode('utf-8'))
+                flags[d] = 1
+        self._build_native(docs, flags)
+
+    def _short_key_string(self):
+        if self._short_keys is None:
+            self._short_keys = [k.lower() for k in self.normalizer.abbreviations.keys() if len(k.lower()) < 2]
+        return ''.join(k for k in self._short_keys if len(k) == 1 and k.isascii())
 
     def _build(self, tokenized):
-        vocab = {}
-        n_tokens = sum(len(d) for d in tokenized)
-        term_ids = np.empty(n_tokens, np.int64)
-        doc_ids = np.empty(n_tokens, np.int64)
-        doc_len = np.empty(len(tokenized), np.int64)
-        at = 0
-        for d, doc in enumerate(tokenized):
-            doc_len[d] = len(doc)
-            for w in doc:
-                t = vocab.get(w)
-                if t is None:
-                    t = len(vocab)
-                    vocab[w] = t
-                term_ids[at] = t
-                doc_ids[at] = d
-                at += 1
+        """Build from token lists (a loaded index file's `tokenized_corpus`)."""
+        docs = ['\n'.join(doc).encode('utf-8') for doc in tokenized]
+        self._build_native(docs, np.ones(len(docs), np.uint8))
+
+    def _build_native(self, docs, flags):
+        term_ids, doc_len, words = rag_hip.bm25_tokenize(docs, flags, self._short_key_string())
+        vocab = {w: i for i, w in enumerate(words)}
+        self._words = words
+        self._doc_tokens = (term_ids, np.concatenate([[0], np.cumsum(doc_len)]))
+        self._tokenized_corpus = None
+        doc_ids = np.repeat(np.arange(len(docs), dtype=np.int64), doc_len)
         # the counting and the sort into term-major order run on the GPU (same arrays as build_arrays)
         self.bm25 = build_arrays_device(term_ids, doc_ids, doc_len, vocab, self.k1, self.b)
         self._upload()
+
+    @property
+    def tokenized_corpus(self):
+        """Token lists of the indexed chunks (the reference keeps them and pickles them); materialised from the
+        native build's id arrays on first use."""
+        if self._tokenized_corpus is None:
+            if self._doc_tokens is None:
+                return []
+            ids, off = self._doc_tokens
+            words = self._words
+            self._tokenized_corpus = [[words[t] for t in ids[off[d]:off[d + 1]]] for d in range(len(off) - 1)]
+        return self._tokenized_corpus
+
+    @tokenized_corpus.setter
+    def tokenized_corpus(self, value):
+        self._tokenized_corpus = value
+        self._doc_tokens = None
 
     def _upload(self):
         a = self.bm25

@@ -72,9 +72,14 @@ SIGNATURES = {
     'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
-    'rag_enc_linear_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_filter_mask_dev': (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    'rag_dense_reserve': (_i32, [_vp, _i32, _i32]),
+    'rag_bm25_reserve': (_i32, [_vp, _i32, _i32, _i32]),
+    'rag_bm25_tokenize_create': (_i32, [C.c_char_p, _vp, _vp, _i64, C.c_char_p, _i32, C.POINTER(_vp)]),
+    'rag_bm25_tokenize_sizes': (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'rag_bm25_tokenize_fetch': (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    'rag_bm25_tokenize_destroy': (None, [_vp]),
     'rag_bm25_build_dev': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     'rag_bm25_impacts_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     'rag_enc_linear384_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
@@ -273,6 +278,10 @@ class DenseIndex:
                                      cnt.ctypes.data), 'rag_dense_search')
         return score, row, cnt
 
+    def reserve(self, max_queries, max_k):
+        """Size the work buffers now: searches within these bounds then never allocate (rag_dense_reserve)."""
+        check(lib().rag_dense_reserve(self._h, int(max_queries), min(int(max_k), MAX_K)), 'rag_dense_reserve')
+
     def search_dev(self, queries, k, row_mask=None, out=None):
         """torch CUDA tensors in/out, asynchronous on the current stream."""
         import torch
@@ -361,6 +370,39 @@ class RowFilter:
         return mask
 
 
+def bm25_tokenize(docs, pretokenized, short_keys=''):
+    """Native tokenizer + vocabulary of the BM25 index build (rag_bm25_tokenize_*; host code, no GPU).
+    docs: list of bytes objects, one per document: the document's ASCII text, or, where pretokenized[d] is
+    true, its tokens (UTF-8) joined by b'\\n'.  short_keys: the one-character lower-cased abbreviation keys as
+    one str.  Returns (term_ids int32 [n_tokens], doc_len int64 [n_docs], vocabulary: list of str in id order)."""
+    n_docs = len(docs)
+    doc_off = np.zeros(n_docs + 1, np.int64)
+    if n_docs:
+        np.cumsum(np.fromiter((len(d) for d in docs), np.int64, n_docs), out=doc_off[1:])
+    text = b''.join(docs)
+    flags = np.ascontiguousarray(np.asarray(pretokenized, dtype=np.uint8)) if n_docs else np.zeros(0, np.uint8)
+    if flags.shape[0] != n_docs:
+        raise ValueError("pretokenized must have one entry per document")
+    keys = short_keys.encode('ascii', 'ignore')
+    h = _vp()
+    check(load_library().rag_bm25_tokenize_create(text, doc_off.ctypes.data, flags.ctypes.data if n_docs else None, n_docs, keys,
+                                         len(keys), C.byref(h)), 'rag_bm25_tokenize_create')
+    try:
+        n_tok, n_voc, n_bytes = _i64(0), _i64(0), _i64(0)
+        check(load_library().rag_bm25_tokenize_sizes(h, C.byref(n_tok), C.byref(n_voc), C.byref(n_bytes)), 'rag_bm25_tokenize_sizes')
+        term_ids = np.empty(n_tok.value, np.int32)
+        doc_len = np.empty(n_docs, np.int64)
+        vbytes = np.empty(max(n_bytes.value, 1), np.uint8)
+        voff = np.empty(n_voc.value + 1, np.int64)
+        check(load_library().rag_bm25_tokenize_fetch(h, term_ids.ctypes.data, doc_len.ctypes.data, vbytes.ctypes.data,
+                                            voff.ctypes.data), 'rag_bm25_tokenize_fetch')
+    finally:
+        load_library().rag_bm25_tokenize_destroy(h)
+    raw = vbytes.tobytes()
+    vocab = [raw[voff[i]:voff[i + 1]].decode('utf-8') for i in range(n_voc.value)]
+    return term_ids, doc_len, vocab
+
+
 def bm25_build_dev(term, doc_off, vocab):
     """Tokenised documents on the device -> term-major CSR on the device (rag_bm25_build_dev).
     term int32 [n_tokens] (document-major, negative ids ignored), doc_off int64 [n_docs+1];
@@ -433,6 +475,10 @@ class Bm25Index:
         check(lib().rag_bm25_search(self._h, terms.ctypes.data, off.ctypes.data, b, int(k), score.ctypes.data,
                                     row.ctypes.data, cnt.ctypes.data), 'rag_bm25_search')
         return score, row, cnt
+
+    def reserve(self, max_queries, max_terms_total, max_k):
+        """Size the work buffers now: searches within these bounds then never allocate (rag_bm25_reserve)."""
+        check(lib().rag_bm25_reserve(self._h, int(max_queries), int(max_terms_total), min(int(max_k), MAX_K)), 'rag_bm25_reserve')
 
     def search_dev(self, qterms, qoff, n_terms_total, k, out=None):
         import torch
@@ -892,7 +938,6 @@ def enc_gelu_(x):
     return x
 
 
-EPILOGUE_BIAS, EPILOGUE_BIAS_GELU, EPILOGUE_BIAS_RESIDUAL_LAYERNORM = 0, 1, 2
 
 
 def enc_mlp_supported(x, w1, w2):
@@ -998,31 +1043,6 @@ def enc_norm_mlp_dev(proj, x, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps=
     check(lib().rag_enc_norm_mlp_dev(_ptr(proj, bf), _ptr(x, bf), _ptr(gamma1, bf), _ptr(beta1, bf), _ptr(w1, bf),
                                      _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma2, bf), _ptr(beta2, bf),
                                      float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()), 'rag_enc_norm_mlp_dev')
-    return y
-
-
-def enc_linear_supported(x, weight):
-    import torch
-    return (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[1] % 64 == 0
-            and weight.shape[0] % 384 == 0)
-
-
-def enc_linear_dev(x, weight, bias, epilogue=EPILOGUE_BIAS, residual=None, gamma=None, beta=None, eps=1e-12):
-    """y = tail(x @ weight.T + bias) with the tail fused into the GEMM (rag_enc_linear_dev);
-    x [M, K] bf16, weight [N, K] bf16."""
-    import torch
-    m, k = x.shape
-    n = weight.shape[0]
-    if weight.shape[1] != k or tuple(bias.shape) != (n,):
-        raise ValueError("weight must be [N, K] and bias [N]")
-    if epilogue == EPILOGUE_BIAS_RESIDUAL_LAYERNORM:
-        if residual is None or tuple(residual.shape) != (m, n) or tuple(gamma.shape) != (n,) or tuple(beta.shape) != (n,):
-            raise ValueError("the LayerNorm tail needs residual [M, N], gamma [N] and beta [N]")
-    y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
-    bf = torch.bfloat16
-    check(lib().rag_enc_linear_dev(_ptr(x, bf), _ptr(weight, bf), _ptr(bias, bf), m, k, n, int(epilogue),
-                                   _ptr(residual, bf), _ptr(gamma, bf), _ptr(beta, bf), float(eps), DTYPE_BF16, _ptr(y),
-                                   _stream()), 'rag_enc_linear_dev')
     return y
 
 

@@ -53,6 +53,7 @@ extern "C" {
 
 typedef struct rag_dense_s* rag_dense_t;
 typedef struct rag_bm25_s*  rag_bm25_t;
+typedef struct rag_tokenized_s* rag_tokenized_t;
 
 /* ---- library ----------------------------------------------------------------- */
 
@@ -105,6 +106,10 @@ int rag_dense_enable_split(rag_dense_t h, int32_t enable);
 int rag_dense_profile(rag_dense_t h, int32_t enable);
 int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_n, int32_t* out_n);
 
+/* Grow the handle's work buffers now to what searches of up to max_queries queries and max_k results need, so that
+ * later rag_dense_search_dev calls within those bounds never call hipMalloc / hipFree (a serving loop, a second
+ * stream, a graph capture).  No counterpart in the reference.                                          */
+int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max_k);
 /* queries [n_queries x dim] fp32 (already normalised for cosine).  row_mask: NULL or
  * one byte per LOCAL row, 0 = excluded (the payload filter of
  * vector_indexer.py:185-196).  Outputs [n_queries x k]; out_count[q] = entries valid. */
@@ -145,6 +150,23 @@ int rag_bm25_create(const int64_t* indptr, const uint32_t* rows, const double* i
                     const double* idf, int64_t n_docs, int64_t vocab, int32_t mem_kind,
                     int64_t row_base, rag_bm25_t* out);
 int rag_bm25_destroy(rag_bm25_t h);
+/* Host side of the index build, native: tokenizer and vocabulary in one pass over the corpus bytes
+ * (BM25Indexer.tokenize and the tokenising loop of BM25Indexer.index_chunks, reference
+ * src/indexing/bm25_indexer.py:50-78 and :92-100).  text holds the documents back to back (UTF-8),
+ * doc_off[n_docs+1] their byte offsets.  A document with pretokenized[d] == 0 (or pretokenized NULL) must be
+ * ASCII and is tokenised here: lower-cased, maximal runs of [a-z0-9_] (what re.findall(r'\b\w+\b') yields on
+ * ASCII text), tokens of one character dropped unless the character is one of short_keys[n_short_keys] (the
+ * one-character lower-cased abbreviation keys) and occurs in the document.  A document with pretokenized[d] != 0
+ * is taken as already tokenised by the caller, its tokens separated by '\n' (how documents outside ASCII come in:
+ * Unicode word classes and case folding are left to the caller).  Vocabulary ids are given in order of first
+ * appearance over the corpus.  No GPU work.  Fetch the result with the two calls below (NULL skips an output):
+ * term_ids[n_tokens] document after document (the d_term of rag_bm25_build_dev), doc_len[n_docs],
+ * vocab_bytes / vocab_off[n_vocab+1] the vocabulary's tokens back to back.                          */
+int rag_bm25_tokenize_create(const char* text, const int64_t* doc_off, const uint8_t* pretokenized, int64_t n_docs,
+                             const char* short_keys, int32_t n_short_keys, rag_tokenized_t* out);
+int rag_bm25_tokenize_sizes(rag_tokenized_t h, int64_t* n_tokens, int64_t* n_vocab, int64_t* vocab_bytes);
+int rag_bm25_tokenize_fetch(rag_tokenized_t h, int32_t* term_ids, int64_t* doc_len, char* vocab_bytes, int64_t* vocab_off);
+void rag_bm25_tokenize_destroy(rag_tokenized_t h);
 /* Index build on the device (the counting that rank_bm25's BM25Okapi constructor does behind
  * BM25Indexer.index_chunks, reference src/indexing/bm25_indexer.py:92-106): tokenised documents
  * -> term-major CSR.  d_term[n_tokens] holds the term ids document after document (negative =
@@ -171,6 +193,9 @@ int64_t rag_bm25_docs(rag_bm25_t h);
 int rag_bm25_search_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff,
                         int32_t n_queries, int32_t n_terms_total, int32_t k,
                         double* d_out_score, int64_t* d_out_row, int32_t* d_out_count, void* stream);
+/* The same for BM25: work buffers for up to max_queries queries with max_terms_total query tokens in all and
+ * max_k results, so that rag_bm25_search_dev within those bounds allocates nothing.                  */
+int rag_bm25_reserve(rag_bm25_t h, int32_t max_queries, int32_t max_terms_total, int32_t max_k);
 int rag_bm25_search(rag_bm25_t h, const int32_t* qterms, const int32_t* qoff, int32_t n_queries,
                     int32_t k, double* out_score, int64_t* out_row, int32_t* out_count);
 /* rag_bm25_search_dev for callers that cannot allocate device memory (code under HIP graph capture,
@@ -341,19 +366,6 @@ int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const i
 int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq,
                           int64_t total_tokens, int32_t hidden, int32_t normalize, float* d_out,
                           void* stream);
-/* Dense layer with its elementwise tail fused into the GEMM epilogue (bf16, fp32
- * accumulation): y[m][n] = tail(sum_k x[m][k] w[n][k] + bias[n]), x [m][k], w [n][k] as
- * nn.Linear stores it; k a multiple of 64, n a multiple of 384.  Tails:
- *   RAG_EPILOGUE_BIAS                     y = v
- *   RAG_EPILOGUE_BIAS_GELU                y = GELU(v)            (exact erf form)
- *   RAG_EPILOGUE_BIAS_RESIDUAL_LAYERNORM  y = LayerNorm(v + residual[m]) * gamma + beta, n == 384
- * y must not alias x; it may alias residual.                                            */
-#define RAG_EPILOGUE_BIAS 0
-#define RAG_EPILOGUE_BIAS_GELU 1
-#define RAG_EPILOGUE_BIAS_RESIDUAL_LAYERNORM 2
-int rag_enc_linear_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t k,
-                       int32_t n, int32_t epilogue, const void* d_residual, const void* d_gamma,
-                       const void* d_beta, float eps, int32_t dtype, void* d_y, void* stream);
 /* Feed-forward block of a BERT layer in one kernel (bf16, fp32 accumulation):
  *   y[m] = LayerNorm(x[m] + GELU(x[m] w1^T + b1) w2^T + b2) * gamma + beta
  * x, y [m][hidden]; w1 [intermediate][hidden], w2 [hidden][intermediate] as nn.Linear stores

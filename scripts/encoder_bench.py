@@ -67,30 +67,6 @@ def main():
     print(f'gelu (PyTorch): {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s ({gb:.2f} GB)', flush=True)
     ms = timed(lambda: rag_hip.enc_gelu_(ff), args.iters)
     print(f'gelu (in place): {ms:.3f} ms, {gb / ms * 1e3:.0f} GB/s ({gb:.2f} GB)', flush=True)
-    # the layer's GEMMs: library GEMM + separate tail kernels against the fused GEMM
-    for name, k, n, epi in (('qkv', h, 3 * h, rag_hip.EPILOGUE_BIAS), ('attn_out + residual + LN', h, h, 2),
-                            ('ffn_in + GELU', h, 4 * h, 1), ('ffn_out + residual + LN', 4 * h, h, 2)):
-        a = torch.randn((t, k), generator=g, device=dev).to(torch.bfloat16)
-        lin = torch.nn.Linear(k, n, device=dev, dtype=torch.bfloat16)
-        r2 = res if n == h else None
-
-        def unfused():
-            y = lin(a)
-            if epi == 1:
-                return rag_hip.enc_gelu_(y)
-            if epi == 2:
-                return rag_hip.enc_add_layernorm_dev(y, r2, gamma, beta, 1e-12)
-            return y
-
-        def fused():
-            return rag_hip.enc_linear_dev(a, lin.weight, lin.bias, epi, r2, gamma if epi == 2 else None,
-                                          beta if epi == 2 else None, 1e-12)
-        with torch.no_grad():
-            ms_u = timed(unfused, args.iters)
-            ms_f = timed(fused, args.iters)
-        fl = 2.0 * t * k * n
-        print(f'{name}: K={k} N={n}: library+tail {ms_u:.3f} ms, fused {ms_f:.3f} ms '
-              f'({fl / ms_f / 1e9:.0f} TFLOP/s)', flush=True)
     # the whole feed-forward block: two library GEMMs + GELU + residual/LayerNorm kernels against one kernel
     if h == 384:
         l1 = torch.nn.Linear(h, 4 * h, device=dev, dtype=torch.bfloat16)

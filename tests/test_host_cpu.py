@@ -67,6 +67,46 @@ def test_tokenizer_keeps_single_character_abbreviation_keys():
     assert 'k' in ix.tokenize(text) and 'x' not in ix.tokenize(text)
 
 
+def test_native_tokenizer_and_vocabulary_match_the_python_tokenizer():
+    """rag_bm25_tokenize_* (host C++ in librag_hip.so, no GPU): ASCII documents tokenised natively, the others handed
+    over as tokens; term ids, document lengths and first-appearance vocabulary equal what the Python loop gives on
+    the reference's tokenizer fixture and on random ASCII text with punctuation, digits, underscores and control
+    characters."""
+    import rag_hip
+    from indexing.bm25_indexer import BM25Indexer
+    from preprocessing import MedicalTermNormalizer
+    norm = MedicalTermNormalizer()
+    norm.abbreviations = dict(norm.abbreviations, K='potassium', x='times')
+    ix = BM25Indexer(medical_normalizer=norm)
+    rng = np.random.default_rng(7)
+    alphabet = list("abcXYZ019_ -.,;:/()\t\n\x00'\"?!kKxX")
+    texts = [c['text'] for c in GOLD['tokenize']] + ['serum K 5 x level', 'K', 'x', '_', 'a_b c__d 9 99', '']
+    texts += [''.join(alphabet[int(j)] for j in rng.integers(0, len(alphabet), int(rng.integers(0, 80)))) for _ in range(300)]
+    want_tokens = [ix.tokenize(t) for t in texts]          # the Python tokenizer (itself pinned by the reference's fixture)
+    vocab, want_ids = {}, []
+    for doc in want_tokens:
+        want_ids.append([vocab.setdefault(w, len(vocab)) for w in doc])
+    docs, flags = [], []
+    for t in texts:
+        if t.isascii():
+            docs.append(t.encode('ascii'))
+            flags.append(0)
+        else:
+            docs.append('\n'.join(ix.tokenize(t)).encode('utf-8'))
+            flags.append(1)
+    assert 0 < sum(flags) < len(flags)
+    ids, doc_len, words = rag_hip.bm25_tokenize(docs, flags, ix._short_key_string())
+    assert words == list(vocab)
+    assert doc_len.tolist() == [len(d) for d in want_tokens]
+    assert ids.tolist() == [t for d in want_ids for t in d]
+    # a non-ASCII document that is not marked as tokenised is refused, not mangled
+    with pytest.raises(rag_hip.RagHipError, match='non-ASCII'):
+        rag_hip.bm25_tokenize(['caf\u00e9'.encode('utf-8')], [0])
+    # empty corpus
+    ids, doc_len, words = rag_hip.bm25_tokenize([], [])
+    assert ids.shape == (0,) and doc_len.shape == (0,) and words == []
+
+
 def test_bm25_indexer_matches_oracle(backend, tmp_path):
     from indexing.bm25_indexer import BM25Indexer
     chunks = make_chunks(300)
