@@ -555,6 +555,28 @@ def main():
         el = time.perf_counter() - t1
         extra['host_buffers'] = {'value': round(args.batch * len(hq) / el, 2), 'ms_per_step': round(el / len(hq) * 1e3, 3),
                                  'note': 'H2D of the query tensors and D2H of rows / scores inside the timed region'}
+        # index build (not part of a query step): the BM25 side of scripts/build_index.py on this shard's documents
+        from indexing.bm25_indexer import build_arrays_device
+        t1 = time.perf_counter()
+        arr2 = build_arrays_device(host['term'], host['doc'], host['ln'], args.vocab, 1.5, 0.75, device=dev)
+        torch.cuda.synchronize()
+        t_csr = time.perf_counter() - t1
+        words = ['w%05d' % i for i in range(20000)]
+        rng_t = np.random.default_rng(3)
+        n_txt = 50_000
+        picks = np.minimum(rng_t.zipf(1.2, size=n_txt * 45) - 1, len(words) - 1)
+        texts = [' '.join(words[j] for j in picks[i * 45:(i + 1) * 45]).encode('ascii') for i in range(n_txt)]
+        t1 = time.perf_counter()
+        ids_t, len_t, voc_t = rag_hip.bm25_tokenize(texts, np.zeros(n_txt, np.uint8))
+        t_tok = time.perf_counter() - t1
+        extra['index_build'] = {
+            'bm25_postings_build_s': round(t_csr, 3), 'documents': int(host['ln'].shape[0]), 'tokens': int(host['term'].shape[0]),
+            'postings': int(arr2.rows.shape[0]),
+            'note': 'term-id stream -> term-major CSR + fp64 impacts on the device (rag_bm25_build_dev, rag_bm25_impacts_dev), '
+                    'host copies included',
+            'native_tokenizer_mtokens_per_s': round(ids_t.shape[0] / t_tok / 1e6, 2),
+            'native_tokenizer_sample': '%d ASCII documents, %d tokens, one host core (rag_bm25_tokenize_*)' % (n_txt, ids_t.shape[0])}
+        del arr2
         result['secondary'] = extra
 
     if args.cpu_queries > 0 and world == 1:
