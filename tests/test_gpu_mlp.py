@@ -240,3 +240,48 @@ def test_cross_encoder_fp32_forward_same_with_and_without_the_fused_output_kerne
         m.bert.fused_split_out = False
         b = m.forward_packed(ids, types, pos, cu, int(lens.max()))
     assert float((a - b).abs().max()) < 1e-6
+
+
+def test_linear_ln_split_argument_errors_and_row_independence():
+    """Limits of rag_enc_linear_ln_split_dev / rag_enc_linear_ln_split_pack_dev are refused with an error (no launch);
+    rows do not influence each other (a row count that ends inside a 128-row tile, rows past the end never written)."""
+    import ctypes as C
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(77)
+    k = 96
+    w = torch.randn((384, k), generator=g, device=dev) * 0.05
+    wh, wl = rag_hip.split_weight_halves(w)
+    b1 = torch.zeros((k,), device=dev)
+    b2, gamma, beta = torch.zeros((384,), device=dev), torch.ones((384,), device=dev), torch.zeros((384,), device=dev)
+    h = torch.randn((200, k), generator=g, device=dev)
+    res = torch.randn((200, 384), generator=g, device=dev)
+    y_all, s_all = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12)
+    for m in (1, 127, 129, 199):
+        y, s = rag_hip.enc_linear_ln_split_dev(h[:m].contiguous(), b1, wh, wl, b2, res[:m].contiguous(), gamma, beta, 1e-12)
+        assert torch.equal(y, y_all[:m]) and torch.equal(s, s_all[:m])
+    # outputs larger than the row count keep their tail: nothing is written past row m
+    lib = rag_hip.load_library()
+    y_buf = torch.full((130, 384), 7.0, device=dev)
+    s_buf = torch.full((130, 1152), 3.0, dtype=torch.float16, device=dev)
+    f = lambda t: C.c_void_p(t.data_ptr())
+    args = lambda m_, k_, n_, wh_=wh: (f(h), 0, f(b1), f(wh_), f(wl), f(b2), f(res), f(gamma), f(beta), C.c_float(1e-12), m_, k_,
+                                         n_, f(y_buf), f(s_buf), None)
+    torch.cuda.synchronize()
+    assert lib.rag_enc_linear_ln_split_dev(*args(100, k, 384)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y_buf[:100], y_all[:100]) and bool((y_buf[100:] == 7.0).all()) and bool((s_buf[100:] == 3.0).all())
+    # limits
+    assert lib.rag_enc_linear_ln_split_dev(*args(100, k, 383)) == rag_hip.lib().rag_enc_linear_ln_split_dev(*args(100, k, 383)) != 0
+    assert 'output width' in rag_hip.last_error()
+    assert lib.rag_enc_linear_ln_split_dev(*args(100, 40, 384)) != 0 and 'multiple of 32' in rag_hip.last_error()
+    assert lib.rag_enc_linear_ln_split_dev(*args(100, 4096, 384)) != 0
+    assert lib.rag_enc_linear_ln_split_dev(*args(-1, k, 384)) != 0
+    assert lib.rag_enc_linear_ln_split_dev(*args(0, k, 384)) == 0                       # nothing to do
+    odd = torch.empty((384 * k + 8,), dtype=torch.float16, device=dev)[1:]            # 2-byte offset: not 16-byte aligned
+    assert lib.rag_enc_linear_ln_split_dev(*args(100, k, 384, odd)) != 0 and 'aligned' in rag_hip.last_error()
+    assert lib.rag_enc_linear_ln_split_pack_dev(f(w), 40, 384, f(wh), f(wl), None) != 0
+    assert lib.rag_enc_linear_ln_split_pack_dev(f(w), k, 100, f(wh), f(wl), None) != 0
+    with pytest.raises(ValueError):
+        rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res[:10], gamma, beta, 1e-12)
+    rag_hip.check_faults()
