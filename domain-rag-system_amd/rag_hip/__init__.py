@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librag_hip.so')
+LIB_PATH = os.environ.get('RAG_HIP_LIB') or os.path.join(_HERE, 'librag_hip.so')     # the override is for A/B builds of a kernel
 
 METRIC_COSINE, METRIC_DOT, METRIC_EUCLID = 0, 1, 2
 MEM_HOST_COPY, MEM_DEVICE_COPY, MEM_DEVICE_BORROW = 0, 1, 2
