@@ -364,7 +364,8 @@ def main():
     scan_s = float(np.mean(scan_ms)) / 1e3 if len(scan_ms) else float('nan')
     achieved = flops / scan_s / 1e12
     dense_peak = MFMA_BF16_PEAK_TFLOPS if dense.split else MFMA_F32_PEAK_TFLOPS
-    roofline = {'kernel': 'dense_scan_kernel (%s)' % ('split-bf16 products, fp32 accumulation' if dense.split else 'fp32'),
+    roofline = {'kernel': '%s (%s)' % ('dense_scan_dma_kernel' if dense.split and args.batch >= 256 else 'dense_scan_kernel',
+                                       'split-bf16 products, fp32 accumulation' if dense.split else 'fp32'),
                 'bound': 'mfma', 'achieved': round(achieved, 2),
                 'peak': dense_peak, 'unit': 'TFLOP/s', 'frac': round(achieved / dense_peak, 4),
                 'traffic': None, 'avg_launch_ms': round(scan_s * 1e3, 3),

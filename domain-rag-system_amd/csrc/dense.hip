@@ -20,6 +20,7 @@
 
 #include <math.h>
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 namespace {
@@ -30,7 +31,7 @@ typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;          // k-slice per stage
 constexpr int LDK = BK + 4;     // padded LDS row (floats): conflict-free ds_read_b128
-constexpr int BN = 128;         // rows per tile
+constexpr int BN_MAX = 256;     // rows per tile: 128 or 256, by tile configuration
 
 struct DenseScanParams {
     const float* rows;          // [n_rows][dim] fp32, or the split image of the same size (see split_rows_kernel)
@@ -41,10 +42,12 @@ struct DenseScanParams {
     int dim;
     int n_queries;
     int k;                      // wanted per query
-    int cap;                    // candidate list capacity per (block, query), >= k + BN
+    int kpub;                   // entries a strip may publish per query (the stride of cand): 2 k, so that the
+                                // last tile rarely has to cut a list; in the threshold pre-pass the groups of a strip
+    int cap;                    // candidate list capacity per (block, query), >= k + rows per tile
     int n_strips;               // multiple of 8
     int n_qblocks;
-    int64_t strip_rows;         // multiple of BN
+    int64_t strip_rows;         // multiple of the rows per tile
     uint2* scratch;             // [n_blocks][BQ][cap]  (key, local row)
     uint2* cand;                // [n_queries][n_strips][k]
     int32_t* cand_count;        // [n_queries][n_strips]
@@ -53,6 +56,7 @@ struct DenseScanParams {
     int euclid;
     int split;                  // rows and queries are split images
     int debug_row_mod;          // tuning aid: when > 0, row loads wrap at this many rows (results meaningless)
+    int maxima;                 // threshold pre-pass: publish the largest score of every 16-row group, keep no lists
 };
 
 template <int WQ, int TQ, int WR, int TR>
@@ -60,7 +64,8 @@ struct DenseCfg {
     static constexpr int NW = WQ * WR;
     static constexpr int NT = NW * 64;
     static constexpr int BQ = WQ * TQ * 32;
-    static_assert(WR * TR * 32 == BN, "row tile must be BN rows");
+    static constexpr int BN = WR * TR * 32;
+    static_assert(BN == 128 || BN == BN_MAX, "row tile of 128 or 256 rows");
     static constexpr int E_LOADS = BN * (BK / 4) / NT;
     static constexpr int Q_LOADS = (BQ * (BK / 4) + NT - 1) / NT;
     static constexpr size_t LDS_BYTES =
@@ -100,8 +105,180 @@ __device__ inline uint32_t wave_compact(uint2* list, int n, int K, uint32_t* sel
     return kmin;
 }
 
-// SPLIT: rows and queries are split images: each 32-wide k-slice of a row (128 bytes either way) holds the
-// bf16 high parts of its 32 values, then the bf16 low parts (x = hi + lo up to 2^-17 relative).  The
+// End of a row tile: every score of the [rows x queries] accumulator tile that reaches its query's running
+// threshold joins that query's candidate list; lists that could overflow in the next tile are cut back to their
+// K best (which raises the threshold); the accumulators are cleared.  Called by all waves of the workgroup
+// (holds one barrier; the caller adds one behind it).
+template <typename Cfg, bool EUCLID, int TQ, int TR>
+__device__ __forceinline__ void tile_epilogue(const DenseScanParams& p, f32x16 (&acc)[TQ][TR], int tile, int n_tiles,
+                                              int64_t row_begin, int64_t row_end, int q0, int wq, int wr, int wave,
+                                              int lane, int strip, int* cnt_s, float* tau_s, uint32_t* sel_s,
+                                              uint2* my_scratch) {
+    constexpr int BN = Cfg::BN, BQ = Cfg::BQ, NW = Cfg::NW;
+    const int lrow = lane & 31;
+    // ---- tile epilogue: D[i][j], i = row (register + lane half), j = query (lane & 31)
+    const int64_t trow0 = row_begin + (int64_t)tile * BN;
+    const int rows_in_tile = (int)min((int64_t)BN, row_end - trow0);
+    const int rbase = wr * TR * 32 + 4 * (lane >> 5);
+    if (p.maxima) {
+        // Threshold pre-pass.  A lane holds 16 rows of a sub-tile for its query: the largest of them is the score
+        // of one real row, and the groups are disjoint, so the K-th largest of a query's group maxima is reached
+        // by K rows — a lower bound of its final K-th score, found without keeping any list.
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq) {
+            const int ql = (wq * TQ + tq) * 32 + lrow;
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[tq][tr][r];
+                    if (EUCLID && rl < rows_in_tile) v = 2.0f * v - p.row_norm2[trow0 + rl];
+                    if (rl < rows_in_tile) m = fmaxf(m, v);
+                    acc[tq][tr][r] = 0.f;
+                }
+                if (q0 + ql < p.n_queries) {
+                    const int g = tile * (BN / 16) + (wr * TR + tr) * 2 + (lane >> 5);
+                    p.cand[((size_t)(q0 + ql) * p.n_strips + strip) * p.kpub + g] =
+                        make_uint2(f32_to_key(m), (uint32_t)(trow0 + rbase + tr * 32));
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) {
+        const int ql = (wq * TQ + tq) * 32 + lrow;
+        const bool qvalid = q0 + ql < p.n_queries && p.debug_row_mod >= 0;
+        const float tauq = tau_s[ql];
+        uint2* list = my_scratch + (size_t)ql * p.cap;
+        if (EUCLID) {
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                    if (rl < rows_in_tile) acc[tq][tr][r] = 2.0f * acc[tq][tr][r] - p.row_norm2[trow0 + rl];
+                }
+        }
+        if (p.row_mask == nullptr) {
+            // a lane counts what it will append from its column of all TR sub-tiles, reserves that many
+            // places with one LDS atomic and then only stores: no round trip per candidate
+            int n = 0;
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                    n += (rl < rows_in_tile && acc[tq][tr][r] >= tauq) ? 1 : 0;
+                }
+            if (!qvalid) n = 0;
+            if (__ballot(n > 0)) {
+                int slot = n > 0 ? atomicAdd(&cnt_s[ql], n) : 0;
+                if (n > 0 && slot + n > p.cap) rag_flag(p.fault, RAG_FAULT_DENSE_LIST);
+#pragma unroll
+                for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                        const float sc = acc[tq][tr][r];
+                        if (n > 0 && rl < rows_in_tile && sc >= tauq) {
+                            if (slot < p.cap) list[slot] = make_uint2(f32_to_key(sc), (uint32_t)(trow0 + rl));
+                            ++slot;
+                        }
+                    }
+            }
+        } else {
+            // with a row mask a candidate is known only after its mask byte is read: one place at a time
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr) {
+                const f32x16& a = acc[tq][tr];
+                float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
+                m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
+                const bool any = qvalid && m >= tauq;
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
+                        const float sc = a[r];
+                        if (any && rl < rows_in_tile && sc >= tauq) {
+                            const uint32_t grow = (uint32_t)(trow0 + rl);
+                            if (p.row_mask[grow]) {
+                                int slot = atomicAdd(&cnt_s[ql], 1);
+                                if (slot < p.cap)
+                                    list[slot] = make_uint2(f32_to_key(sc), grow);
+                                else
+                                    rag_flag(p.fault, RAG_FAULT_DENSE_LIST);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tq][tr][r] = 0.f;
+    }
+    __syncthreads();
+    // ---- lists that could overflow in the next tile are cut back to their K best
+    const bool last_tile = tile == n_tiles - 1;
+    for (int base = wave * (BQ / NW); base < (wave + 1) * (BQ / NW); base += 64) {
+        int ql = base + lane;
+        bool need = false;
+        if (ql < (wave + 1) * (BQ / NW)) {
+            int c = cnt_s[ql];
+            need = last_tile ? c > p.kpub : c > p.cap - BN;
+        }
+        unsigned long long m = __ballot(need);
+        while (m) {
+            int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int q = base + b;
+            int n = min(cnt_s[q], p.cap);
+            uint32_t kmin = wave_compact(my_scratch + (size_t)q * p.cap, n, p.k,
+                                         sel_s + wave * RAG_SEL_LDS_WORDS, lane);
+            if (lane == 0) {
+                cnt_s[q] = p.k;
+                tau_s[q] = key_to_f32(kmin);
+                // K rows of this strip reach kmin, so the final K-th score does too
+                if (q0 + q < p.n_queries) atomicMax(&p.tau_shared[q0 + q], kmin);
+            }
+        }
+        // adopt the best lower bound any strip has published for this query
+        if (!last_tile && ql < (wave + 1) * (BQ / NW) && q0 + ql < p.n_queries) {
+            uint32_t g = __hip_atomic_load(&p.tau_shared[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float tg = key_to_f32(g);
+            if (tg > tau_s[ql]) tau_s[ql] = tg;
+        }
+    }
+}
+
+// End of a strip: the workgroup's lists (cut to K entries by the last tile's epilogue) go to their places in
+// cand; in the threshold pre-pass the group maxima are there already and only their number is recorded.
+template <typename Cfg>
+__device__ __forceinline__ void publish_strip(const DenseScanParams& p, int n_tiles, int q0, int wave, int lane, int strip,
+                                              const int* cnt_s, const uint2* my_scratch) {
+    constexpr int BQ = Cfg::BQ, NW = Cfg::NW;
+    for (int ql = wave * (BQ / NW); ql < (wave + 1) * (BQ / NW); ++ql) {
+        const int q = q0 + ql;
+        if (q >= p.n_queries) break;
+        if (p.maxima) {
+            if (lane == 0) p.cand_count[(size_t)q * p.n_strips + strip] = n_tiles * (Cfg::BN / 16);
+            continue;
+        }
+        const int n = min(cnt_s[ql], p.kpub);
+        uint2* dst = p.cand + ((size_t)q * p.n_strips + strip) * p.kpub;
+        const uint2* src = my_scratch + (size_t)ql * p.cap;
+        for (int i = lane; i < n; i += 64) dst[i] = src[i];
+        if (lane == 0) p.cand_count[(size_t)q * p.n_strips + strip] = n;
+    }
+}
+
+// SPLIT: rows and queries are split images: each 16 values of a row (64 bytes either way) are held as their 16
+// bf16 high parts, then their 16 bf16 low parts (x = hi + lo up to 2^-17 relative).  The
 // score tile is then hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32 accumulation: three
 // v_mfma_f32_32x32x16_bf16 per 16 values of k instead of eight v_mfma_f32_32x32x2_f32, at a fifth of the
 // matrix time, with the same loads, LDS image and epilogue.  What is dropped (lo.lo) is below 2^-16 of
@@ -109,7 +286,7 @@ __device__ inline uint32_t wave_compact(uint2* list, int n, int K, uint32_t* sel
 template <int WQ, int TQ, int WR, int TR, bool EUCLID, bool SPLIT>
 __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanParams p) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
-    constexpr int NT = Cfg::NT, NW = Cfg::NW, BQ = Cfg::BQ;
+    constexpr int NT = Cfg::NT, BQ = Cfg::BQ, BN = Cfg::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Es = reinterpret_cast<float*>(smem_raw);                 // [2][BN][LDK]
     float* Qs = Es + 2 * BN * LDK;                                  // [2][BQ][LDK]
@@ -220,19 +397,19 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // lane (row, half) feeds k = 16s + 8*half + 0..7 of the slice: 16 bytes of the high parts,
-                // 16 bytes of the low parts 64 bytes further on
+                // 16 bytes of the low parts 32 bytes further on
                 bf16x8 ah[TR], al[TR], bh[TQ], bl[TQ];
 #pragma unroll
                 for (int tr = 0; tr < TR; ++tr) {
-                    const float* src = eb + ((wr * TR + tr) * 32 + lrow) * LDK + 8 * s + khalf;
+                    const float* src = eb + ((wr * TR + tr) * 32 + lrow) * LDK + 16 * s + khalf;
                     ah[tr] = *reinterpret_cast<const bf16x8*>(src);
-                    al[tr] = *reinterpret_cast<const bf16x8*>(src + 16);
+                    al[tr] = *reinterpret_cast<const bf16x8*>(src + 8);
                 }
 #pragma unroll
                 for (int tq = 0; tq < TQ; ++tq) {
-                    const float* src = qbuf + ((wq * TQ + tq) * 32 + lrow) * LDK + 8 * s + khalf;
+                    const float* src = qbuf + ((wq * TQ + tq) * 32 + lrow) * LDK + 16 * s + khalf;
                     bh[tq] = *reinterpret_cast<const bf16x8*>(src);
-                    bl[tq] = *reinterpret_cast<const bf16x8*>(src + 16);
+                    bl[tq] = *reinterpret_cast<const bf16x8*>(src + 8);
                 }
 #pragma unroll
                 for (int tq = 0; tq < TQ; ++tq)
@@ -276,81 +453,8 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
 
         const int tile = st / k_stages;
         if (st - tile * k_stages == k_stages - 1) {
-            // ---- tile epilogue: D[i][j], i = row (register + lane half), j = query (lane & 31)
-            const int64_t trow0 = row_begin + (int64_t)tile * BN;
-            const int rows_in_tile = (int)min((int64_t)BN, row_end - trow0);
-            const int rbase = wr * TR * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int tq = 0; tq < TQ; ++tq) {
-                const int ql = (wq * TQ + tq) * 32 + lrow;
-                const bool qvalid = q0 + ql < p.n_queries;
-                const float tauq = tau_s[ql];
-#pragma unroll
-                for (int tr = 0; tr < TR; ++tr) {
-                    f32x16& a = acc[tq][tr];
-                    if (EUCLID) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
-                            if (rl < rows_in_tile) a[r] = 2.0f * a[r] - p.row_norm2[trow0 + rl];
-                        }
-                    }
-                    float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7])));
-                    m = fmaxf(m, fmaxf(fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11])), fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]))));
-                    const bool any = qvalid && m >= tauq && p.debug_row_mod >= 0;
-                    if (__ballot(any)) {             // rare once the threshold has warmed up
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rl = rbase + tr * 32 + (r & 3) + 8 * (r >> 2);
-                            const float sc = a[r];
-                            if (any && rl < rows_in_tile && sc >= tauq) {
-                                const uint32_t grow = (uint32_t)(trow0 + rl);
-                                if (p.row_mask == nullptr || p.row_mask[grow]) {
-                                    int slot = atomicAdd(&cnt_s[ql], 1);
-                                    if (slot < p.cap)
-                                        my_scratch[(size_t)ql * p.cap + slot] = make_uint2(f32_to_key(sc), grow);
-                                    else
-                                        rag_flag(p.fault, RAG_FAULT_DENSE_LIST);
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a[r] = 0.f;
-                }
-            }
-            __syncthreads();
-            // ---- lists that could overflow in the next tile are cut back to their K best
-            const bool last_tile = tile == n_tiles - 1;
-            for (int base = wave * (BQ / NW); base < (wave + 1) * (BQ / NW); base += 64) {
-                int ql = base + lane;
-                bool need = false;
-                if (ql < (wave + 1) * (BQ / NW)) {
-                    int c = cnt_s[ql];
-                    need = last_tile ? c > p.k : c > p.cap - BN;
-                }
-                unsigned long long m = __ballot(need);
-                while (m) {
-                    int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    int q = base + b;
-                    int n = min(cnt_s[q], p.cap);
-                    uint32_t kmin = wave_compact(my_scratch + (size_t)q * p.cap, n, p.k,
-                                                 sel_s + wave * RAG_SEL_LDS_WORDS, lane);
-                    if (lane == 0) {
-                        cnt_s[q] = p.k;
-                        tau_s[q] = key_to_f32(kmin);
-                        // K rows of this strip reach kmin, so the final K-th score does too
-                        if (q0 + q < p.n_queries) atomicMax(&p.tau_shared[q0 + q], kmin);
-                    }
-                }
-                // adopt the best lower bound any strip has published for this query
-                if (!last_tile && ql < (wave + 1) * (BQ / NW) && q0 + ql < p.n_queries) {
-                    uint32_t g = __hip_atomic_load(&p.tau_shared[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    float tg = key_to_f32(g);
-                    if (tg > tau_s[ql]) tau_s[ql] = tg;
-                }
-            }
+            tile_epilogue<Cfg, EUCLID, TQ, TR>(p, acc, tile, n_tiles, row_begin, row_end, q0, wq, wr, wave, lane, strip, cnt_s, tau_s,
+                                               sel_s, my_scratch);
             __syncthreads();
         }
 
@@ -358,19 +462,235 @@ __global__ __launch_bounds__(WQ * WR * 64, 2) void dense_scan_kernel(DenseScanPa
         __syncthreads();
     }
 
-    // ---- publish this strip's lists
-    for (int ql = wave * (BQ / NW); ql < (wave + 1) * (BQ / NW); ++ql) {
-        const int q = q0 + ql;
-        if (q >= p.n_queries) break;
-        const int n = min(cnt_s[ql], p.k);
-        uint2* dst = p.cand + ((size_t)q * p.n_strips + strip) * p.k;
-        const uint2* src = my_scratch + (size_t)ql * p.cap;
-        for (int i = lane; i < n; i += 64) dst[i] = src[i];
-        if (lane == 0) p.cand_count[(size_t)q * p.n_strips + strip] = n;
-    }
+    publish_strip<Cfg>(p, n_tiles, q0, wave, lane, strip, cnt_s, my_scratch);
 }
 
-// fp32 [n][dim] -> split image [n][dim / 32][hi x 32 | lo x 32] bf16 (dim a multiple of 32): one thread per
+// One wave-instruction of a direct-to-LDS load: lane l's 16 bytes at gbase + voff land at LDS byte
+// lds_dst + 16 l.  M0 carries the destination and belongs to the compiler, so it is saved and restored inside
+// the statement.  The compiler does not count this load: wait with s_waitcnt vmcnt before reading.
+__device__ __forceinline__ void lds_dma16(uint32_t lds_dst, const void* gbase, uint32_t voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gbase) : "memory");
+}
+
+// LDS reads whose completion the SOURCE waits for, so that they can run a group of MFMAs ahead of their use (the
+// compiler issues a fragment read right before the MFMA that needs it and waits for it there).  lds_read16 only
+// issues; the value is defined after an lds_wait8<N> that names the register, with N = the number of LDS reads
+// issued after it (LDS reads complete in order; anything else the compiler has in flight on the same counter
+// only makes the wait stricter).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read16(u32x4& dst, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait8(u32x4 (&a)[4], u32x4 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N));
+}
+template <int... Is, typename F>
+__device__ __forceinline__ void unrolled(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// The split scan for batches of 256 queries and more: a [256 rows x 256 queries] tile per workgroup of eight
+// waves (two per SIMD, 128 accumulator registers each), so 16 values of k bring 32 KiB into LDS for 24 MFMAs
+// per wave where the [128 x 256] tile of dense_scan_kernel brings 24 KiB for 12 — the scan is bound by how
+// fast a CU can fill its LDS, not by the matrix cores.  The slices (16 NS values of k) go straight from L2 to
+// LDS (direct-to-LDS loads, no staging registers) into a ring of RING buffers, RING - 1 slices ahead of the one
+// being multiplied; one barrier per slice.  A row of a buffer is the slice itself (NS x [hi x 16 | lo x 16]);
+// its 16-byte pieces are XOR-swizzled with low row bits instead of padded (conflict-free ds_read_b128).
+// Measured at 1M x 768, 1024 queries: NS = 2, RING = 2 (128 KiB of buffers) 4.93 ms; NS = 1, RING = 4 (the same
+// bytes, 1.5 x as many in flight, twice the barriers) 5.06 ms.
+// The loads do not check bounds: the caller pads the row image with 256 rows and the query image to whole
+// blocks of 256 queries (scores of rows or queries past the end are computed and never used).
+using DmaCfg = DenseCfg<4, 2, 2, 4>;
+constexpr int DMA_BUF_BYTES = 128 * 1024;                                                // all buffers of the ring
+constexpr size_t DMA_LDS_BYTES = DMA_BUF_BYTES + DmaCfg::BQ * 8 + DmaCfg::NW * RAG_SEL_LDS_WORDS * 4;
+
+template <bool EUCLID, int NS, int DMA_RING>
+__global__ __launch_bounds__(DmaCfg::NT, 2) void dense_scan_dma_kernel(DenseScanParams p) {
+    using Cfg = DmaCfg;
+    constexpr int TQ = 2, TR = 4, WR = 2, NT = Cfg::NT, BQ = Cfg::BQ, BN = Cfg::BN;
+    constexpr int DMA_BK = 16 * NS;                                              // values of k per slice
+    constexpr int ROW_B = DMA_BK * 4;                                            // bytes of a buffer row: 64 or 128
+    constexpr int DMA_STAGE_BYTES = (BN + BQ) * ROW_B;                           // 32 or 64 KiB
+    constexpr int DMA_PER_WAVE = DMA_STAGE_BYTES / 1024 / Cfg::NW;               // loads per wave and slice
+    constexpr int ROWS_PER_DMA = 1024 / ROW_B;                                   // 16 or 8
+    constexpr int GROUP_ROWS = ROWS_PER_DMA * Cfg::NW;                           // rows the eight waves fill at once
+    static_assert((NS == 1 || NS == 2) && DMA_RING * DMA_STAGE_BYTES == DMA_BUF_BYTES && (DMA_RING & (DMA_RING - 1)) == 0,
+                  "ring of 2 x 64 KiB or 4 x 32 KiB");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // [RING buffers][rows 256 x ROW_B | queries 256 x ROW_B], then the per-query counters and thresholds
+    int* cnt_s = reinterpret_cast<int*>(smem_raw + DMA_RING * DMA_STAGE_BYTES);
+    float* tau_s = reinterpret_cast<float*>(cnt_s + BQ);
+    uint32_t* sel_s = reinterpret_cast<uint32_t*>(tau_s + BQ);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave / WR, wr = wave % WR;
+    const int id = blockIdx.x;                        // same mapping as dense_scan_kernel
+    const int xcd = id & 7;
+    const int j = id >> 3;
+    const int qb = j % p.n_qblocks;
+    const int strip = (j / p.n_qblocks) * 8 + xcd;
+    const int q0 = qb * BQ;
+    const int64_t row_begin = (int64_t)strip * p.strip_rows;
+    const int64_t row_end = min(p.n_rows, row_begin + p.strip_rows);
+    uint2* my_scratch = p.scratch + (size_t)blockIdx.x * BQ * p.cap;
+
+    for (int i = tid; i < BQ; i += NT) {
+        cnt_s[i] = 0;
+        tau_s[i] = q0 + i < p.n_queries
+                       ? key_to_f32(__hip_atomic_load(&p.tau_shared[q0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                       : -INFINITY;
+    }
+
+    const int n_tiles = row_begin < row_end ? (int)((row_end - row_begin + BN - 1) / BN) : 0;
+    const int k_stages = p.dim / DMA_BK;
+    const int n_stages = n_tiles * k_stages;
+    const uint32_t stride = (uint32_t)p.dim * 4u;                                // bytes per image row
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+
+    // a wave-instruction fills 1 KiB of a buffer, ROWS_PER_DMA rows.  64-byte rows: lane l -> row l >> 2, stored
+    // piece l & 3 = source piece (l & 3) ^ ((row >> 1) & 3); 128-byte rows: row l >> 3, stored piece l & 7 = source
+    // piece (l & 7) ^ (row & 7).  Wave w fills rows ROWS_PER_DMA w .. of every group of GROUP_ROWS rows.
+    const uint32_t voff = NS == 1 ? (uint32_t)(lane >> 2) * stride + 16u * (uint32_t)((lane & 3) ^ ((lane >> 3) & 3))
+                                  : (uint32_t)(lane >> 3) * stride + 16u * (uint32_t)((lane & 7) ^ ((lane >> 3) & 7));
+    const unsigned char* rows_b =
+        reinterpret_cast<const unsigned char*>(p.rows) + (size_t)(row_begin + ROWS_PER_DMA * wave) * stride;
+    const unsigned char* qrs_b =
+        reinterpret_cast<const unsigned char*>(p.queries) + (size_t)(q0 + ROWS_PER_DMA * wave) * stride;
+    auto dma_stage = [&](int tile, int ks, int buf) {
+        const unsigned char* rb = rows_b + (size_t)tile * BN * stride + ks * ROW_B;
+        const unsigned char* qbp = qrs_b + ks * ROW_B;
+        const uint32_t dst = lds0 + buf * DMA_STAGE_BYTES + 1024 * wave;
+#pragma unroll
+        for (int i = 0; i < BN / GROUP_ROWS; ++i) lds_dma16(dst + 8192 * i, rb + (size_t)i * GROUP_ROWS * stride, voff);
+#pragma unroll
+        for (int i = 0; i < BQ / GROUP_ROWS; ++i)
+            lds_dma16(dst + BN * ROW_B + 8192 * i, qbp + (size_t)i * GROUP_ROWS * stride, voff);
+    };
+    static_assert(BN / GROUP_ROWS + BQ / GROUP_ROWS == DMA_PER_WAVE, "loads per wave and slice");
+
+    f32x16 acc[TQ][TR];
+#pragma unroll
+    for (int a = 0; a < TQ; ++a)
+#pragma unroll
+        for (int b = 0; b < TR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // the load cursor runs DMA_RING - 1 slices ahead; past the last slice it stays there (the same slice is
+    // loaded again into a buffer nobody reads), so every iteration issues the same number of loads and the
+    // count the waits name holds to the end
+    int ltile = 0, lks = 0;
+    auto advance = [&]() {
+        if (lks + 1 < k_stages) ++lks;
+        else if (ltile + 1 < n_tiles) { ++ltile; lks = 0; }
+    };
+    if (n_stages > 0) {
+#pragma unroll
+        for (int i = 0; i < DMA_RING - 1; ++i) {
+            dma_stage(ltile, lks, i);
+            advance();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_RING - 2) * DMA_PER_WAVE) : "memory");
+    __syncthreads();
+
+    // lane (row, half) of sub-step s reads the high parts k = 16 s + 8 half .. + 7 (piece 4 s + half) and the low
+    // parts (piece 4 s + 2 + half) of its row, each piece at its swizzled place
+    const int lrow = lane & 31, half = lane >> 5;
+    const int swz = NS == 1 ? (lrow >> 1) & 3 : lrow & 7;
+    uint32_t a_h[NS], a_l[NS], q_h[NS], q_l[NS];                       // LDS addresses in buffer 0
+#pragma unroll
+    for (int sI = 0; sI < NS; ++sI) {
+        const uint32_t ph = (uint32_t)lrow * ROW_B + 16u * (uint32_t)((4 * sI + half) ^ swz);
+        const uint32_t pl = (uint32_t)lrow * ROW_B + 16u * (uint32_t)((4 * sI + 2 + half) ^ swz);
+        a_h[sI] = lds0 + (wr * TR * 32) * ROW_B + ph;
+        a_l[sI] = lds0 + (wr * TR * 32) * ROW_B + pl;
+        q_h[sI] = lds0 + BN * ROW_B + (wq * TQ * 32) * ROW_B + ph;
+        q_l[sI] = lds0 + BN * ROW_B + (wq * TQ * 32) * ROW_B + pl;
+    }
+
+    // A slice is multiplied in G = 2 NS groups of 12 MFMAs: group g = (sub-step g >> 1, row sub-tiles 2 (g & 1) and
+    // + 1) x both query sub-tiles x the three products, product-major, so an accumulator comes round every fourth
+    // MFMA.  The fragment reads of group g + 1 (four row fragments; with an odd g also the four query fragments of
+    // the next sub-step) are issued before the MFMAs of group g.
+    constexpr int G = 2 * NS;
+    int tile = 0, ks = 0;
+    for (int st = 0; st < n_stages; ++st) {
+        const int buf = st & (DMA_RING - 1);
+        dma_stage(ltile, lks, (st + DMA_RING - 1) & (DMA_RING - 1));
+        advance();
+
+        const uint32_t bo = (uint32_t)buf * DMA_STAGE_BYTES;
+        u32x4 Bf[2][4], Af[2][4];
+        auto read_b = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            lds_read16<0>(Bf[S & 1][0], q_h[S] + bo);
+            lds_read16<32 * ROW_B>(Bf[S & 1][1], q_h[S] + bo);
+            lds_read16<0>(Bf[S & 1][2], q_l[S] + bo);
+            lds_read16<32 * ROW_B>(Bf[S & 1][3], q_l[S] + bo);
+        };
+        auto read_a = [&](auto g_c) {
+            constexpr int GI = decltype(g_c)::value, S = GI >> 1, T0 = 2 * (GI & 1);
+            lds_read16<T0 * 32 * ROW_B>(Af[GI & 1][0], a_h[S] + bo);
+            lds_read16<T0 * 32 * ROW_B>(Af[GI & 1][1], a_l[S] + bo);
+            lds_read16<(T0 + 1) * 32 * ROW_B>(Af[GI & 1][2], a_h[S] + bo);
+            lds_read16<(T0 + 1) * 32 * ROW_B>(Af[GI & 1][3], a_l[S] + bo);
+        };
+        auto group = [&](auto g_c) {
+            constexpr int GI = decltype(g_c)::value, S = GI >> 1, T0 = 2 * (GI & 1);
+            if constexpr ((GI & 1) && GI + 1 < G) read_b(std::integral_constant<int, S + 1>{});
+            if constexpr (GI + 1 < G) read_a(std::integral_constant<int, GI + 1>{});
+            constexpr int newer = (GI + 1 < G ? 4 : 0) + ((GI & 1) && GI + 1 < G ? 4 : 0);
+            lds_wait8<newer>(Bf[S & 1], Af[GI & 1]);
+            const bf16x8 ah0 = __builtin_bit_cast(bf16x8, Af[GI & 1][0]), al0 = __builtin_bit_cast(bf16x8, Af[GI & 1][1]);
+            const bf16x8 ah1 = __builtin_bit_cast(bf16x8, Af[GI & 1][2]), al1 = __builtin_bit_cast(bf16x8, Af[GI & 1][3]);
+            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, Bf[S & 1][0]), bh1 = __builtin_bit_cast(bf16x8, Bf[S & 1][1]);
+            const bf16x8 bl0 = __builtin_bit_cast(bf16x8, Bf[S & 1][2]), bl1 = __builtin_bit_cast(bf16x8, Bf[S & 1][3]);
+            acc[0][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][T0], 0, 0, 0);
+            acc[1][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[1][T0], 0, 0, 0);
+            acc[0][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[0][T0 + 1], 0, 0, 0);
+            acc[1][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[1][T0 + 1], 0, 0, 0);
+            acc[0][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0][T0], 0, 0, 0);
+            acc[1][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[1][T0], 0, 0, 0);
+            acc[0][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[0][T0 + 1], 0, 0, 0);
+            acc[1][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[1][T0 + 1], 0, 0, 0);
+            acc[0][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][T0], 0, 0, 0);
+            acc[1][T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[1][T0], 0, 0, 0);
+            acc[0][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[0][T0 + 1], 0, 0, 0);
+            acc[1][T0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][T0 + 1], 0, 0, 0);
+        };
+        read_b(std::integral_constant<int, 0>{});
+        read_a(std::integral_constant<int, 0>{});
+        unrolled(std::make_integer_sequence<int, G>{}, group);
+
+        if (ks == k_stages - 1) {
+            tile_epilogue<Cfg, EUCLID, TQ, TR>(p, acc, tile, n_tiles, row_begin, row_end, q0, wq, wr, wave, lane, strip, cnt_s,
+                                               tau_s, sel_s, my_scratch);
+            ks = 0;
+            ++tile;
+        } else {
+            ++ks;
+        }
+        // the next slice has landed once at most the loads of the two slices behind it are outstanding
+        // (loads retire in issue order; younger memory operations of the epilogue only make this stricter)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_RING - 2) * DMA_PER_WAVE) : "memory");
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    publish_strip<Cfg>(p, n_tiles, q0, wave, lane, strip, cnt_s, my_scratch);
+}
+
+// fp32 [n][dim] -> split image [n][dim / 16][hi x 16 | lo x 16] bf16 (dim a multiple of 32): one thread per
 // 8 values.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, int64_t n_rows, int dim,
                                                          bf16* __restrict__ out) {
@@ -387,9 +707,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             hi[j] = (bf16)f[j];
             lo[j] = (bf16)(f[j] - (float)hi[j]);
         }
-        bf16* o = out + row * 2 * dim + (c >> 2) * 64 + (c & 3) * 8;
+        bf16* o = out + row * 2 * dim + (c >> 1) * 32 + (c & 1) * 8;
         *reinterpret_cast<bf16x8*>(o) = hi;
-        *reinterpret_cast<bf16x8*>(o + 32) = lo;
+        *reinterpret_cast<bf16x8*>(o + 16) = lo;
     }
 }
 
@@ -574,11 +894,16 @@ extern "C" int rag_dense_enable_split(rag_dense_t h, int32_t enable) {
     }
     RAG_REQUIRE(h->dim % 32 == 0, RAG_EINVAL, "rag_dense_enable_split: dim %d is not a multiple of 32", h->dim);
     if (h->rows_split || h->n_rows == 0) return RAG_OK;
-    const size_t bytes = (size_t)h->n_rows * h->dim * sizeof(float);
+    // 256 rows of zeros behind the image: dense_scan_dma_kernel loads whole tiles
+    const size_t bytes = (size_t)(h->n_rows + BN_MAX) * h->dim * sizeof(float);
     hipError_t e = hipMalloc((void**)&h->rows_split, bytes);
+    if (e == hipSuccess) {
+        e = hipMemset((char*)h->rows_split + (size_t)h->n_rows * h->dim * sizeof(float), 0, (size_t)BN_MAX * h->dim * sizeof(float));
+        if (e != hipSuccess) (void)hipFree(h->rows_split);
+    }
     if (e != hipSuccess) {
         h->rows_split = nullptr;
-        rag_set_error("rag_dense_enable_split: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        rag_set_error("rag_dense_enable_split: allocating %zu bytes failed: %s", bytes, hipGetErrorString(e));
         return RAG_ENOMEM;
     }
     const int64_t n8 = h->n_rows * (h->dim / 8);
@@ -634,17 +959,19 @@ int plan_scan(rag_dense_t h, DenseScanParams& p) {
     const int per_cu = (int)((160 * 1024) / Cfg::LDS_BYTES) > 0 ? (int)((160 * 1024) / Cfg::LDS_BYTES) : 1;
     const int resident = 256 * (per_cu > 4 ? 4 : per_cu);
     int64_t want_strips = (resident + p.n_qblocks - 1) / p.n_qblocks;
+    constexpr int BN = Cfg::BN;
     int64_t max_strips = ceil_div64(p.n_rows, BN);
     if (want_strips > max_strips) want_strips = max_strips;
     if (want_strips < 1) want_strips = 1;
     p.strip_rows = ceil_div64(ceil_div64(p.n_rows, want_strips), BN) * BN;
     int64_t strips = ceil_div64(p.n_rows, p.strip_rows);
     p.n_strips = (int)(ceil_div64(strips, 8) * 8);
+    p.kpub = p.maxima ? (int)(p.strip_rows / 16) : (2 * p.k < p.cap ? 2 * p.k : p.cap);
     const int64_t n_blocks = (int64_t)p.n_strips * p.n_qblocks;
 
     int rc = h->scratch.ensure((size_t)n_blocks * Cfg::BQ * p.cap * sizeof(uint2));
     if (rc) return rc;
-    rc = h->cand.ensure((size_t)p.n_queries * p.n_strips * p.k * sizeof(uint2));
+    rc = h->cand.ensure((size_t)p.n_queries * p.n_strips * p.kpub * sizeof(uint2));
     if (rc) return rc;
     rc = h->cand_count.ensure((size_t)p.n_queries * p.n_strips * sizeof(int32_t));
     if (rc) return rc;
@@ -660,17 +987,25 @@ int dense_dispatch(int n_queries, F&& f) {
     return f(std::integral_constant<int, 3>{});
 }
 
-int dense_cap(int k) {
-    int cap = 2 * k + BN;
-    if (cap < 3 * BN) cap = 3 * BN;
+// rows of the threshold pre-pass: at least 64 K, in whole tiles of either height
+int64_t prepass_rows(int k) {
+    int64_t n = 16384;
+    if (const char* e = getenv("RAG_DENSE_SAMPLE")) n = atoll(e) > 0 ? atoll(e) : n;      // tuning aid
+    if (n < 64 * (int64_t)k) n = 64 * (int64_t)k;
+    return (n + BN_MAX - 1) / BN_MAX * BN_MAX;
+}
+
+int dense_cap(int k) {                                   // holds for either tile height
+    int cap = 2 * k + BN_MAX;
+    if (cap < 3 * BN_MAX) cap = 3 * BN_MAX;
     if (const char* e = getenv("RAG_DENSE_CAP")) {      // tuning aid: candidate list capacity
         int v = atoi(e);
-        if (v >= k + BN && v <= 8192) cap = v;
+        if (v >= k + BN_MAX && v <= 8192) cap = v;
     }
     return (cap + 63) / 64 * 64;
 }
 
-template <int WQ, int TQ, int WR, int TR>
+template <int WQ, int TQ, int WR, int TR, bool DMA = false>
 int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool preset_tau = false) {
     using Cfg = DenseCfg<WQ, TQ, WR, TR>;
     int rc = plan_scan<WQ, TQ, WR, TR>(h, p);
@@ -684,10 +1019,19 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool pres
     p.cand = (uint2*)h->cand.p;
     p.cand_count = (int32_t*)h->cand_count.p;
 
-    auto kern = p.split ? (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, true> : dense_scan_kernel<WQ, TQ, WR, TR, false, true>)
-                        : (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, false> : dense_scan_kernel<WQ, TQ, WR, TR, false, false>);
-    RAG_GRANT_LDS(kern, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    if constexpr (DMA) {
+        static_assert(std::is_same<Cfg, DmaCfg>::value, "the direct-to-LDS scan has one tile shape");
+        static const bool ring4 = getenv("RAG_DENSE_RING4") != nullptr;     // tuning aid: 4 x 32 KiB buffers
+        auto kern = ring4 ? (p.euclid ? dense_scan_dma_kernel<true, 1, 4> : dense_scan_dma_kernel<false, 1, 4>)
+                          : (p.euclid ? dense_scan_dma_kernel<true, 2, 2> : dense_scan_dma_kernel<false, 2, 2>);
+        RAG_GRANT_LDS(kern, DMA_LDS_BYTES);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), DMA_LDS_BYTES, stream, p);
+    } else {
+        auto kern = p.split ? (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, true> : dense_scan_kernel<WQ, TQ, WR, TR, false, true>)
+                            : (p.euclid ? dense_scan_kernel<WQ, TQ, WR, TR, true, false> : dense_scan_kernel<WQ, TQ, WR, TR, false, false>);
+        RAG_GRANT_LDS(kern, Cfg::LDS_BYTES);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, p);
+    }
     RAG_HIP_TRY(hipGetLastError());
     h->last_strips = p.n_strips;
     h->last_qblocks = p.n_qblocks;
@@ -720,11 +1064,13 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     p.dim = h->dim;
     p.n_queries = n_queries;
     p.k = k;
+    p.kpub = k;
     p.cap = dense_cap(k);
     p.euclid = h->metric == RAG_METRIC_EUCLID;
     p.split = 0;
     if (h->rows_split && !getenv("RAG_DENSE_NO_SPLIT")) {
-        int rc0 = h->queries_split.ensure((size_t)n_queries * h->dim * sizeof(float));
+        // whole blocks of 256 queries: dense_scan_dma_kernel loads whole tiles (what lies past the batch is never used)
+        int rc0 = h->queries_split.ensure(((size_t)n_queries + BN_MAX) * h->dim * sizeof(float));
         if (rc0) return rc0;
         const int64_t n8 = (int64_t)n_queries * (h->dim / 8);
         split_rows_kernel<<<(unsigned)(n8 / 256 + 1 > 65536 ? 65536 : n8 / 256 + 1), 256, 0, stream>>>(
@@ -735,6 +1081,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         p.split = 1;
     }
     p.debug_row_mod = 0;
+    p.maxima = 0;
     p.fault = rag_fault_word();
     if (const char* e = getenv("RAG_DENSE_ROW_MOD")) p.debug_row_mod = atoi(e);
     int rc;
@@ -744,6 +1091,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
             if constexpr (C == 0) return launch_scan<1, 1, 4, 1>(h, pp, stream, preset);
             else if constexpr (C == 1) return launch_scan<1, 2, 4, 1>(h, pp, stream, preset);
             else if constexpr (C == 2) return launch_scan<2, 2, 2, 2>(h, pp, stream, preset);
+            else if (pp.split && !getenv("RAG_DENSE_NO_DMA")) return launch_scan<4, 2, 2, 4, true>(h, pp, stream, preset);
             else return launch_scan<4, 2, 2, 2>(h, pp, stream, preset);
         });
     };
@@ -752,7 +1100,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     // compacts candidates only for rows that beat the pre-pass's K-th score instead of letting
     // each of its strips find a threshold from -inf on its own.  The result is the same exact
     // top-K: the threshold is reached by K real rows.
-    const int64_t sample = ((int64_t)16384 > 64 * (int64_t)k ? 16384 : 64 * (int64_t)k + BN - 1) / BN * BN;
+    const int64_t sample = prepass_rows(k);
     // timing aid: one event pair around everything the scan does (pre-pass included), not the final merge
     const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING;
     if (prof) RAG_HIP_TRY(hipEventRecord(h->ev0[h->prof_n], stream));
@@ -760,8 +1108,10 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     if (prepass) {
         DenseScanParams p0 = p;
         p0.n_rows = sample;
+        // without a row mask the pre-pass keeps no lists: the K-th largest of the 16-row group maxima is the bound
+        p0.maxima = d_row_mask == nullptr && !getenv("RAG_DENSE_LIST_PREPASS");
         if ((rc = scan(p0, false))) return rc;
-        if ((rc = launch_merge_cand32(p0.cand, p0.cand_count, n_queries, p0.n_strips, k, k, h->row_base, d_out_score,
+        if ((rc = launch_merge_cand32(p0.cand, p0.cand_count, n_queries, p0.n_strips, p0.kpub, k, h->row_base, d_out_score,
                                       d_out_row, d_out_count, p.fault, stream)))
             return rc;
         tau_from_topk_kernel<<<(n_queries + 255) / 256, 256, 0, stream>>>(d_out_score, d_out_count, n_queries, k,
@@ -785,7 +1135,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         float* t_score = (float*)h->tmp_score.p;
         int64_t* t_row = (int64_t*)h->tmp_row.p;
         int32_t* t_count = (int32_t*)h->tmp_count.p;
-        rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, t_score, t_row,
+        rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, p.kpub, k, h->row_base, t_score, t_row,
                                  t_count, p.fault, stream);
         if (rc) return rc;
         dense_rescore_kernel<<<(unsigned)ceil_div64((int64_t)nk, 4), 256, 0, stream>>>(
@@ -797,7 +1147,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         RAG_HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, k, k, h->row_base, d_out_score,
+    rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, p.kpub, k, h->row_base, d_out_score,
                              d_out_row, d_out_count, p.fault, stream);
     if (rc) return rc;
     if (p.euclid) {
@@ -813,11 +1163,13 @@ extern "C" int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max
                 "rag_dense_reserve: need max_queries >= 1 and 1 <= max_k <= %d (got %d, %d)", RAG_MAX_K, max_queries, max_k);
     if (h->n_rows == 0) return RAG_OK;
     // every tile configuration a batch of up to max_queries can run (the work buffers are sized by the configuration)
-    const int sizes[] = {1, 32, 64, 255, max_queries};
-    for (int nq : sizes) {
+    const int sizes[] = {1, 32, 64, 255, max_queries, -255, -max_queries};      // negative: the pre-pass of that batch
+    for (int nqs : sizes) {
+        const int nq = nqs < 0 ? -nqs : nqs;
         if (nq > max_queries) continue;
         DenseScanParams p = {};
-        p.n_rows = h->n_rows;
+        p.n_rows = nqs < 0 ? (prepass_rows(max_k) < h->n_rows ? prepass_rows(max_k) : h->n_rows) : h->n_rows;
+        p.maxima = nqs < 0;
         p.n_queries = nq;
         p.k = max_k;
         p.cap = dense_cap(max_k);
@@ -826,12 +1178,15 @@ extern "C" int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max
             if constexpr (C == 0) return plan_scan<1, 1, 4, 1>(h, p);
             else if constexpr (C == 1) return plan_scan<1, 2, 4, 1>(h, p);
             else if constexpr (C == 2) return plan_scan<2, 2, 2, 2>(h, p);
-            else return plan_scan<4, 2, 2, 2>(h, p);
+            else {
+                int rc3 = h->rows_split ? plan_scan<4, 2, 2, 4>(h, p) : RAG_OK;
+                return rc3 ? rc3 : plan_scan<4, 2, 2, 2>(h, p);
+            }
         });
         if (rc) return rc;
     }
     int rc;
-    if (h->rows_split && (rc = h->queries_split.ensure((size_t)max_queries * h->dim * sizeof(float)))) return rc;
+    if (h->rows_split && (rc = h->queries_split.ensure(((size_t)max_queries + BN_MAX) * h->dim * sizeof(float)))) return rc;
     const size_t nk = (size_t)max_queries * max_k;
     if ((rc = h->tmp_score.ensure(nk * sizeof(float)))) return rc;
     if ((rc = h->tmp_row.ensure(nk * sizeof(int64_t)))) return rc;

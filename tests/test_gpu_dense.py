@@ -119,6 +119,32 @@ def test_dense_split_scores_stay_within_5e6_of_the_fp32_scan():
     assert not rag_hip.DenseIndex(np.zeros((4, 48), np.float32)).split
 
 
+def test_dense_wide_batches_take_the_same_rows_on_every_path(monkeypatch):
+    """256 queries and more run the [256 x 256] direct-to-LDS scan, and over 262144 rows a threshold pre-pass in
+    front of it (group maxima without a row mask, candidate lists with one).  Each of these can be switched off by
+    an environment variable: the results must not change, and must match the oracle with a mask and for the
+    Euclidean metric too."""
+    import rag_hip
+    n, dim, b, k = 270_000, 64, 300, 10
+    corpus = synth.dense_corpus(n, dim, seed=31)
+    queries = synth.dense_queries(corpus, b, seed=32)
+    idx = rag_hip.DenseIndex(corpus)
+    assert idx.split
+    base = idx.search(queries, k)
+    for var in ('RAG_DENSE_LIST_PREPASS', 'RAG_DENSE_NO_PREPASS', 'RAG_DENSE_NO_DMA', 'RAG_DENSE_RING4'):
+        monkeypatch.setenv(var, '1')
+        other = idx.search(queries, k)
+        monkeypatch.delenv(var)
+        for x, y in zip(base, other):
+            assert np.array_equal(x, y), var
+    rng = np.random.default_rng(1)
+    mask = (rng.random(n) < 0.3).astype(np.uint8)
+    _check_index(idx, corpus, queries[:260], k, 'cosine', mask, False)
+    idx.close()
+    _check(corpus[:20_000], queries[:257], k, metric='euclidean')
+    _check(corpus[:100], queries[:256], 7)
+
+
 def test_dense_rescore_matches_scores():
     import rag_hip
     corpus = synth.dense_corpus(2000, 768, seed=8)
