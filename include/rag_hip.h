@@ -91,7 +91,7 @@ int rag_dense_create(const float* rows, int64_t n_rows, int32_t dim, int32_t met
                      int32_t mem_kind, int64_t row_base, rag_dense_t* out);
 int rag_dense_destroy(rag_dense_t h);
 int64_t rag_dense_rows(rag_dense_t h);
-/* enable != 0: keep a second image of the rows (same size) in which every value is split into bf16
+/* enable != 0: keep a second image of the rows (same size plus 256 rows) in which every value is split into bf16
  * high and low parts, and run searches as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with fp32
  * accumulation (queries are split per search).  Those scores differ from the fp32 products by at most
  * 2^-16 |row||query| (1e-7 to 1e-6 for unit vectors) and only choose the rows: the scores returned
