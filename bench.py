@@ -104,7 +104,7 @@ def build_shard(args, rank, world, dev, dist):
     t0 = time.time()
     term, doc, ln = synth.sparse_corpus(n, v, seed=2000 + rank)
     stats = None
-    if world > 1:
+    if dist is not None:
         df = np.bincount(np.unique(term * n + doc) // n, minlength=v).astype(np.int64)
         tdf = torch.from_numpy(df).to(dev)
         tot = torch.tensor([int(ln.sum()), n], dtype=torch.int64, device=dev)
@@ -120,7 +120,7 @@ def build_shard(args, rank, world, dev, dist):
     off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(clen, 0)
     tok = torch.randint(1000, 30522, (int(off[-1]),), generator=g, device=dev, dtype=torch.int32)
-    if world > 1:                       # replicate the token store (small) so any rank can pack any pair
+    if dist is not None:                # replicate the token store (small) so any rank can pack any pair
         lens = [torch.empty_like(clen) for _ in range(world)]
         dist.all_gather(lens, clen)
         sizes = [int(l.sum()) for l in lens]
@@ -248,7 +248,10 @@ def main():
         local = 0
         import faulthandler                      # a rank that waits forever shows where
         faulthandler.dump_traceback_later(100, repeat=True)
-    if world > 1:
+    # RAG_DIST_FORCE=1: the process group and every exchange also with a single rank (launched through
+    # torch.distributed.run --nproc-per-node 1): drives the RCCL code path on a one-GPU box
+    force = os.environ.get('RAG_DIST_FORCE') == '1' and 'RANK' in os.environ
+    if world > 1 or force:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if rehearse:

@@ -86,6 +86,9 @@ class BatchSearcher:
         self.rank = dist.get_rank() if dist is not None else 0
         if dist is not None:
             self.split_embed = os.environ.get('RAG_SPLIT_EMBED') != '0'
+        # the exchanges run whenever there is more than one rank; RAG_DIST_FORCE=1 runs them with a single rank too
+        # (every collective is then an identity): the only way to drive the RCCL branch of this file on a one-GPU box
+        self.sharded = dist is not None and (self.world > 1 or os.environ.get('RAG_DIST_FORCE') == '1')
         self.times = StageTimes()
         self.timing = False
         # read the device-side consistency flags after every batch and raise if a kernel met inconsistent data
@@ -117,7 +120,7 @@ class BatchSearcher:
         """Query embeddings [B, dim].  Sharded: every rank has all the queries, so each embeds one slice of
         them and the slices are all-gathered (B x dim floats) instead of every rank embedding all of them."""
         b = ids.shape[0]
-        if self.world > 1 and self.split_embed and b >= self.world:
+        if self.sharded and self.split_embed and b >= self.world:
             per = (b + self.world - 1) // self.world
             lo, hi = min(b, self.rank * per), min(b, (self.rank + 1) * per)
             mine = self._embed_local(ids[lo:hi].contiguous(), mask[lo:hi].contiguous()) if hi > lo else None
@@ -165,7 +168,7 @@ class BatchSearcher:
     def _gather_merge(self, score, row, cnt, k, smaller_is_better=False):
         """all-gather the per-shard lists and merge them to the global top-k (smaller_is_better: lists of
         distances, as a Euclidean index returns them)."""
-        if self.world == 1:
+        if not self.sharded:
             return score, row, cnt
         b = score.shape[0]
         kk = score.shape[1]
@@ -219,7 +222,7 @@ class BatchSearcher:
                 self._ce_packed(q_tok, q_off, my_q, my_r, plen, logits_mine)
             else:
                 self._ce_padded(q_tok, q_off, my_q, my_r, plen, logits_mine)
-        if self.world > 1:
+        if self.sharded:
             gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
             self._all_gather(gathered, logits_mine)
             logits = gathered[:n_pairs]
@@ -374,7 +377,7 @@ class BatchSearcher:
         score comes from the rank that holds it (the others report 0 for it), summed over the ranks."""
         b, t = fused_row.shape
         scores = self.dense.rescore_dev(qvec.contiguous(), fused_row.contiguous())
-        if self.world > 1:
+        if self.sharded:
             self._all_reduce_sum(scores)
         seg_off = torch.zeros((b + 1,), dtype=torch.int32, device=fused_row.device)
         seg_off[1:] = torch.cumsum(fused_cnt, 0)
@@ -421,7 +424,7 @@ class BatchSearcher:
         argument tuples of ``search``; returns the list of its result dicts.  With more than one
         rank the batches run one after the other: the retrieval half contains collectives, and
         one communicator must not be driven from two streams at once."""
-        if self.world > 1 or self.cross_encoder is None or len(batches) < 2 or self.timing:
+        if self.sharded or self.cross_encoder is None or len(batches) < 2 or self.timing:
             return [self.search(*b) for b in batches]
         main = torch.cuda.current_stream()
         if self._side_stream is None:
