@@ -10,8 +10,9 @@ in HBM when the timed region starts.  Prints ONE JSON line (rank 0).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 With N > 1 the corpus rows are sharded (each rank holds --rows rows: weak scaling in corpus
-size), per-shard top-k lists are all-gathered over RCCL and merged, and the cross-encoder
-pairs are split across the ranks.
+size) and a step is one batch of --batch x N queries: every rank searches its rows for all of
+them, the per-shard top-k lists are all-gathered over RCCL and merged, and the cross-encoder
+pairs are split across the ranks (--batch x rerank_top_n pairs per GPU whatever N is).
 """
 import argparse
 import json
@@ -36,7 +37,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=1024, help='queries per step')
+    ap.add_argument('--batch', type=int, default=1024,
+                    help='queries per step and GPU: a step is one batch of batch x N queries (every rank searches its rows for all\n'
+                         'of them and reranks 1/N of the pairs, so the rerank work per GPU stays fixed as N grows)')
     ap.add_argument('--rows', type=int, default=1_000_000, help='corpus rows per GPU')
     ap.add_argument('--dim', type=int, default=768)
     ap.add_argument('--vocab', type=int, default=200_000)
@@ -75,7 +78,8 @@ def parse():
                     help='run attention and LayerNorm of the cross-encoder as PyTorch ops instead of the librag_hip kernels')
     ap.add_argument('--embed-arch', default='bert-base')
     ap.add_argument('--ce-arch', default='minilm-l6')
-    ap.add_argument('--cpu-queries', type=int, default=4, help='queries timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-queries', type=int, default=32,
+                    help='queries timed on the host for cpu_baseline (0 = skip); 32 are 10-15 s of work on 16 cores')
     ap.add_argument('--stage-times', action='store_true', help='extra untimed pass with per-stage events')
     return ap.parse_args()
 
@@ -239,6 +243,8 @@ def cpu_baseline(args, searcher_models, rows_dev, host, queries, gpu_out):
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    batch_per_gpu = args.batch
+    args.batch = batch_per_gpu * world             # the step's batch: every rank sees all of its queries
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
@@ -466,6 +472,7 @@ def main():
                                'top_k=%d' % (n_total // 1_000_000, args.dim,
                                              ' row-sharded %d ways' % world if world > 1 else '', t, args.top_k),
                    'rows_per_gpu': args.rows, 'rows_total': n_total, 'dim': args.dim, 'batch': args.batch,
+                   'batch_per_gpu': batch_per_gpu, 'global_batch': args.batch,
                    'per_list_k': 2 * t, 'fused': t, 'ce_pairs_per_query': t, 'vocab': args.vocab,
                    'embedder': args.embed_arch, 'cross_encoder': args.ce_arch,
                    'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU',
