@@ -12,7 +12,8 @@
 // Kernel 2 (bm25_tile_kernel): one workgroup per (document tile, query), tiles outermost in the
 // grid.  The tile's fp64 scores live in LDS; the query's tokens are applied one after the other
 // (a barrier in between), so each document's sum is formed in query-token order exactly like the
-// reference's `score += idf * impact` loop: bit-identical fp64 results.  The tile then emits its
+// reference's `score += idf * impact` loop: bit-identical fp64 results.  The next token's postings are
+// already in flight while a token is added.  The tile then emits its
 // candidates for the query's top-K: documents whose score reaches the query's shared threshold,
 // cut to the tile's K best; the K-th best of a tile raises the shared threshold (a lower bound
 // of the final K-th score), which prunes later tiles.  Candidates go to one append-only list per
@@ -32,6 +33,9 @@ namespace {
 
 constexpr int BM_NT = 256;
 constexpr int BM_TILE = 2048;      // documents per tile (16 KB of fp64 accumulators)
+constexpr int BM_TOK = 32;         // query tokens whose posting ranges are looked up in one go
+constexpr int BM_PF = 3;           // postings per thread fetched one token ahead (2, 3, 4 measured alike)
+constexpr int BM_CTR_STRIDE = 32;  // ints between two queries' list counters (128 bytes)
 
 struct Bm25Params {
     const int64_t* indptr;
@@ -51,7 +55,10 @@ struct Bm25Params {
     unsigned long long* tau;       // [n_queries] shared score-key threshold
     uint64_t* cand_key;            // [n_queries][n_tiles * k]: one append-only candidate list per query
     uint32_t* cand_row;
-    int32_t* cand_count;           // [n_queries] candidates appended so far
+    int32_t* cand_count;           // [n_queries] candidates appended so far (read by the merge)
+    int32_t* cand_ctr;             // the counters the tiles add to: one per query, BM_CTR_STRIDE ints apart (a cache
+                                   // line each: thousands of tiles reserve places at the same time, and atomics on
+                                   // one line are served one after the other)
     double* dense_out;             // scores mode: [n_docs]
     int share_tau;                 // tuning aid: 0 = tiles do not share their thresholds
     int tile_base;                 // first tile of this launch
@@ -79,31 +86,44 @@ __global__ void bm25_offsets_kernel(Bm25Params p) {
     p.toff[gid] = result;
 }
 
+// One workgroup per (document tile, query).  SQ counters of this kernel show the SIMDs' issue ports busy all the
+// time (eight waves per SIMD, each issuing 13 % of its life), so the loop is written for few instructions per
+// posting: a token's posting range is wave-uniform (scalar base pointers, 32-bit places: a tile holds at most
+// BM_TILE postings of a token), rows stay 32-bit (below 2^32, checked at create), and a row outside the tile only
+// sets a flag that is looked at once at the end.  The tokens are applied strictly one after the other, a barrier in
+// between (the summation order of the reference), but nothing else waits in that order: posting range and idf of
+// up to BM_TOK tokens are looked up together (one thread per token: term -> indptr / offsets / idf is a chain of
+// dependent loads), and the first BM_PF postings per thread of token j + 1 are in flight while token j is added.
 template <bool SCORES_ONLY>
 __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
-    __shared__ double acc[BM_TILE];
+    __shared__ __attribute__((aligned(16))) double acc[BM_TILE];
     __shared__ __attribute__((aligned(16))) uint32_t sel_lds[RAG_SEL_LDS_WORDS];
-    __shared__ unsigned long long tau_s;
     __shared__ unsigned long long kmin_s;
     __shared__ int count_s[2];
     __shared__ int base_s;
+    __shared__ uint32_t tk_lo[BM_TOK], tk_n[BM_TOK];
+    __shared__ double tk_w[BM_TOK];
 
     const int tid = threadIdx.x;
     const int tile_in_launch = blockIdx.x / p.n_queries;
     const int q = blockIdx.x - tile_in_launch * p.n_queries;
     const int tile = p.tile_base + tile_in_launch;
     const int64_t r0 = (int64_t)tile * BM_TILE;
+    const uint32_t r0u = (uint32_t)r0;
     const int n_in = (int)min((int64_t)BM_TILE, p.n_docs - r0);
+    unsigned long long tau = 0ull;                     // every thread reads the same word: one request per wave
+    if (!SCORES_ONLY && p.share_tau) tau = __hip_atomic_load(&p.tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    for (int i = tid; i < BM_TILE; i += BM_NT) acc[i] = 0.0;
+    {
+        double2* a2 = reinterpret_cast<double2*>(acc);
+#pragma unroll
+        for (int i = 0; i < BM_TILE / 2 / BM_NT; ++i) a2[i * BM_NT + tid] = make_double2(0.0, 0.0);
+    }
     if (tid == 0) {
         count_s[0] = 0;
         count_s[1] = 0;
         kmin_s = ~0ull;
-        tau_s = (SCORES_ONLY || !p.share_tau)
-                    ? 0ull : __hip_atomic_load(&p.tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
 
     int t_begin = p.qoff[q], t_end = p.qoff[q + 1];
     if (t_begin < 0 || t_end > p.n_terms_total) {     // offsets beyond the term array
@@ -112,77 +132,144 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
         t_end = min(t_end, p.n_terms_total);
     }
     const int per = p.n_tiles + 1;
-    for (int ti = t_begin; ti < t_end; ++ti) {
-        const int term = p.qterms[ti];
-        if (term < 0 || term >= p.vocab) continue;    // out of vocabulary: contributes nothing
-        const int64_t base = p.indptr[term];
-        const int64_t lo = base + p.toff[(int64_t)ti * per + tile];
-        const int64_t hi = base + p.toff[(int64_t)ti * per + tile + 1];
-        const double w = p.idf[term];
-        for (int64_t at = lo + tid; at < hi; at += BM_NT) {
-            const int64_t r = (int64_t)p.rows[at] - r0;
-            if (r < 0 || r >= BM_TILE) {               // postings not sorted by row: index is corrupt
-                rag_flag(p.fault, RAG_FAULT_BM25_POSTING);
-                continue;
+    bool bad = false;
+    for (int c0 = t_begin; c0 < t_end; c0 += BM_TOK) {
+        const int nt = min(BM_TOK, t_end - c0);
+        if (c0 != t_begin) __syncthreads();           // the previous chunk's ranges have been read by everyone
+        if (tid < nt) {
+            const int ti = c0 + tid;
+            const int term = p.qterms[ti];
+            uint32_t lo = 0, n = 0;
+            double w = 0.0;
+            if (term >= 0 && term < p.vocab) {        // out of vocabulary: contributes nothing
+                const uint32_t a = p.toff[(int64_t)ti * per + tile], b = p.toff[(int64_t)ti * per + tile + 1];
+                lo = (uint32_t)(p.indptr[term] + a);   // postings are fewer than 2^32 (checked at create)
+                n = b - a;
+                w = p.idf[term];
             }
-            // score += idf * impact, two roundings, no contraction
-            acc[r] = __dadd_rn(acc[r], __dmul_rn(w, p.impact[at]));
+            tk_lo[tid] = lo;
+            tk_n[tid] = n;
+            tk_w[tid] = w;
         }
-        __syncthreads();
+        __syncthreads();                               // (also orders the zeroing above before the first sums)
+        uint32_t nr[BM_PF];
+        double ni[BM_PF];
+        auto fetch = [&](int j) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(tk_lo[j]);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(tk_n[j]);
+            const uint32_t* rows_j = p.rows + lo;
+            const double* imp_j = p.impact + lo;
+#pragma unroll
+            for (int u = 0; u < BM_PF; ++u) {
+                const uint32_t idx = (uint32_t)tid + u * BM_NT;
+                nr[u] = 0xFFFFFFFFu;                   // no posting in this place
+                ni[u] = 0.0;
+                if (idx < n) {
+                    nr[u] = rows_j[idx];
+                    ni[u] = imp_j[idx];
+                }
+            }
+        };
+        auto apply = [&](uint32_t row, double impact, double w) {
+            const uint32_t r = row - r0u;
+            if (r < (uint32_t)BM_TILE) {
+                // score += idf * impact, two roundings, no contraction
+                acc[r] = __dadd_rn(acc[r], __dmul_rn(w, impact));
+            } else {
+                bad |= row != 0xFFFFFFFFu;             // postings not sorted by row: index is corrupt
+            }
+        };
+        fetch(0);
+        for (int j = 0; j < nt; ++j) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(tk_lo[j]);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(tk_n[j]);
+            const double w = tk_w[j];
+            uint32_t cr[BM_PF];
+            double ci[BM_PF];
+#pragma unroll
+            for (int u = 0; u < BM_PF; ++u) {
+                cr[u] = nr[u];
+                ci[u] = ni[u];
+            }
+            if (j + 1 < nt) fetch(j + 1);
+#pragma unroll
+            for (int u = 0; u < BM_PF; ++u) apply(cr[u], ci[u], w);
+            if (n > (uint32_t)(BM_PF * BM_NT)) {       // a token most documents of the tile contain
+                const uint32_t* rows_j = p.rows + lo;
+                const double* imp_j = p.impact + lo;
+                for (uint32_t idx = (uint32_t)tid + BM_PF * BM_NT; idx < n; idx += BM_NT) apply(rows_j[idx], imp_j[idx], w);
+            }
+            __syncthreads();
+        }
     }
+    if (t_begin >= t_end) __syncthreads();             // no token: the zeroing still has to be seen by everyone
+    if (__ballot(bad) && (tid & 63) == 0) rag_flag(p.fault, RAG_FAULT_BM25_POSTING);
 
     if (SCORES_ONLY) {
         for (int i = tid; i < n_in; i += BM_NT) p.dense_out[r0 + i] = acc[i];
         return;
     }
 
-    // ---- how many documents of this tile reach the shared threshold?
-    const unsigned long long tau = tau_s;
-    int mine = 0;
-    for (int i = tid; i < n_in; i += BM_NT) mine += f64_to_key(acc[i]) >= tau ? 1 : 0;
+    // ---- which documents of this tile reach the shared threshold?  Thread t holds documents t, t + 256, ...:
+    // bit i of `mask` = document i * BM_NT + t passes.
+    // (the key order is the order of the doubles themselves, so the comparison is done on them: one instruction
+    // per document instead of the key conversion; key 0, "no threshold yet", lies below every score)
+    constexpr int PER = BM_TILE / BM_NT;
+    const double tau_d = tau ? key_to_f64(tau) : -__builtin_huge_val();
+    uint32_t mask = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((tid & 63) == 0 && mine) atomicAdd(&count_s[0], mine);
+    for (int i = 0; i < PER; ++i) {
+        const int d = i * BM_NT + tid;
+        if (d < n_in && acc[d] >= tau_d) mask |= 1u << i;
+    }
+    {
+        int mine = __popc(mask);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if ((tid & 63) == 0 && mine) atomicAdd(&count_s[0], mine);
+    }
     __syncthreads();
     const int n_pass = count_s[0];
 
     // Reserve this tile's place in the query's candidate list: every document that passes, or the k best.
     const int n_emit = min(n_pass, p.k);
     if (n_emit == 0) return;
-    if (tid == 0) base_s = atomicAdd(&p.cand_count[q], n_emit);
-    __syncthreads();
-    const size_t slot = (size_t)q * p.n_tiles * p.k + base_s;
-    if (n_pass <= p.k) {
-        for (int i = tid; i < n_in; i += BM_NT) {
-            unsigned long long key = f64_to_key(acc[i]);
-            if (key >= tau) {
-                int at = atomicAdd(&count_s[1], 1);
-                if (at < n_emit) {
-                    p.cand_key[slot + at] = key;
-                    p.cand_row[slot + at] = (uint32_t)(r0 + i);
-                }
-            }
-        }
-    } else {
+    if (tid == 0) base_s = atomicAdd(&p.cand_ctr[(size_t)q * BM_CTR_STRIDE], n_emit);
+    unsigned long long kmin = ~0ull;
+    if (n_pass > p.k) {
         auto get = [&](int i, uint64_t& key, uint32_t& row) {
             key = f64_to_key(acc[i]);
             row = (uint32_t)(r0 + i);
         };
         SelThr<uint64_t> thr = radix_select<uint64_t, BM_NT>(get, n_in, p.k, sel_lds, tid);
-        unsigned long long kmin = ~0ull;
-        for (int i = tid; i < n_in; i += BM_NT) {
-            uint64_t key = f64_to_key(acc[i]);
-            uint32_t row = (uint32_t)(r0 + i);
-            if (sel_pass(thr, key, row)) {
-                int at = atomicAdd(&count_s[1], 1);
-                if (at < n_emit) {
-                    p.cand_key[slot + at] = key;
-                    p.cand_row[slot + at] = row;
+        mask = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int d = i * BM_NT + tid;
+            if (d < n_in) {
+                const uint64_t key = f64_to_key(acc[d]);
+                if (sel_pass(thr, key, (uint32_t)(r0 + d))) {
+                    mask |= 1u << i;
+                    kmin = min(kmin, (unsigned long long)key);
                 }
-                kmin = min(kmin, (unsigned long long)key);
             }
         }
         if (kmin != ~0ull) atomicMin(&kmin_s, kmin);
+    }
+    __syncthreads();                                   // base_s
+    const size_t slot = (size_t)q * p.n_tiles * p.k + base_s;
+    if (mask) {
+        int at = atomicAdd(&count_s[1], __popc(mask));
+        while (mask) {
+            const int i = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const int d = i * BM_NT + tid;
+            if (at < n_emit) {
+                p.cand_key[slot + at] = f64_to_key(acc[d]);
+                p.cand_row[slot + at] = (uint32_t)(r0 + d);
+            }
+            ++at;
+        }
     }
     __syncthreads();
     const int n_written = count_s[1];
@@ -190,13 +277,19 @@ __global__ __launch_bounds__(BM_NT) void bm25_tile_kernel(Bm25Params p) {
         // internal error: the reserved places must still hold defined entries (the lowest key, rows of
         // this tile that were not emitted cannot be named here, so the merge may flag the list too)
         if (tid == 0) rag_flag(p.fault, RAG_FAULT_BM25_LIST);
-        for (int i = max(n_written, 0) + tid; i < n_emit; i += BM_NT) {
+        for (int i = max(min(n_written, n_emit), 0) + tid; i < n_emit; i += BM_NT) {
             p.cand_key[slot + i] = 0ull;
             p.cand_row[slot + i] = (uint32_t)r0;
         }
     }
     // only an exact selection proves that k documents reach kmin
     if (tid == 0 && p.share_tau && n_pass > p.k && n_written == p.k) atomicMax(&p.tau[q], kmin_s);
+}
+
+// list counters, one cache line apart -> the dense array the merge reads
+__global__ void bm25_gather_counts_kernel(const int32_t* __restrict__ ctr, int n_queries, int32_t* __restrict__ count) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_queries) count[q] = ctr[(size_t)q * BM_CTR_STRIDE];
 }
 
 // The K-th best score of a merged sample of tiles is a lower bound of the final K-th score: raise the
@@ -347,7 +440,7 @@ struct Bm25WorkBytes {
 Bm25WorkBytes bm25_work_bytes(rag_bm25_t h, int n_queries, int n_terms_total, int k) {
     const size_t slots = (size_t)n_queries * (size_t)ceil_div64(h->n_docs, BM_TILE);
     return {bm25_toff_bytes(h, n_terms_total), (size_t)n_queries * sizeof(unsigned long long), slots * k * sizeof(uint64_t),
-            slots * k * sizeof(uint32_t), (size_t)n_queries * sizeof(int32_t)};
+            slots * k * sizeof(uint32_t), (size_t)n_queries * (BM_CTR_STRIDE + 1) * sizeof(int32_t)};
 }
 
 int bm25_check_search_args(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff, int32_t n_queries,
@@ -382,9 +475,10 @@ int bm25_search_on(rag_bm25_t h, const Bm25Work& w, const int32_t* d_qterms, con
     p.tau = w.tau;
     p.cand_key = w.cand_key;
     p.cand_row = w.cand_row;
-    p.cand_count = w.cand_count;
+    p.cand_ctr = w.cand_count;                                       // [n_queries][BM_CTR_STRIDE], then the dense counts
+    p.cand_count = w.cand_count + (size_t)n_queries * BM_CTR_STRIDE;
     RAG_HIP_TRY(hipMemsetAsync(p.tau, 0, (size_t)n_queries * sizeof(unsigned long long), stream));
-    RAG_HIP_TRY(hipMemsetAsync(p.cand_count, 0, (size_t)n_queries * sizeof(int32_t), stream));
+    RAG_HIP_TRY(hipMemsetAsync(p.cand_ctr, 0, (size_t)n_queries * BM_CTR_STRIDE * sizeof(int32_t), stream));
     const int64_t n_blocks = (int64_t)p.n_tiles * n_queries;
     RAG_REQUIRE(n_blocks < (1ll << 31), RAG_ELIMIT, "rag_bm25_search: %lld workgroups exceed the grid limit",
                 (long long)n_blocks);
@@ -398,6 +492,8 @@ int bm25_search_on(rag_bm25_t h, const Bm25Work& w, const int32_t* d_qterms, con
         p.tile_base = 0;
         bm25_tile_kernel<false><<<(unsigned)((int64_t)sample * n_queries), BM_NT, 0, stream>>>(p);
         RAG_HIP_TRY(hipGetLastError());
+        bm25_gather_counts_kernel<<<(n_queries + 255) / 256, 256, 0, stream>>>(p.cand_ctr, n_queries, p.cand_count);
+        RAG_HIP_TRY(hipGetLastError());
         rc = launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, (int64_t)p.n_tiles * k, k, h->row_base,
                                  d_out_score, d_out_row, d_out_count, p.fault, stream);
         if (rc) return rc;
@@ -406,6 +502,8 @@ int bm25_search_on(rag_bm25_t h, const Bm25Work& w, const int32_t* d_qterms, con
     }
     p.tile_base = sample;
     bm25_tile_kernel<false><<<(unsigned)((int64_t)(p.n_tiles - sample) * n_queries), BM_NT, 0, stream>>>(p);
+    RAG_HIP_TRY(hipGetLastError());
+    bm25_gather_counts_kernel<<<(n_queries + 255) / 256, 256, 0, stream>>>(p.cand_ctr, n_queries, p.cand_count);
     RAG_HIP_TRY(hipGetLastError());
     return launch_merge_cand64(p.cand_key, p.cand_row, p.cand_count, n_queries, (int64_t)p.n_tiles * k, k, h->row_base,
                                d_out_score, d_out_row, d_out_count, p.fault, stream);
