@@ -802,6 +802,7 @@ struct rag_dense_s {
     int64_t row_base = 0;
     int device = 0;
     DevBuf scratch, cand, cand_count, tau_shared;
+    DevBuf grp_score, grp_row, grp_count;      // first level of the two-level strip merge: [n_queries][groups][k]
     // optional timing of the scan kernel: a ring of event pairs on the launch stream
     static constexpr int PROF_RING = 256;
     bool profiling = false;
@@ -879,6 +880,9 @@ extern "C" int rag_dense_destroy(rag_dense_t h) {
     h->cand.release();
     h->cand_count.release();
     h->tau_shared.release();
+    h->grp_score.release();
+    h->grp_row.release();
+    h->grp_count.release();
     delete h;
     return RAG_OK;
 }
@@ -949,6 +953,15 @@ extern "C" int rag_dense_profile_read(rag_dense_t h, float* out_ms, int32_t max_
 
 namespace {
 
+// Strips per group of the two-level list merge, 0 = one level.  A small batch is scanned in about a thousand strips
+// (every CU has to pull on HBM), each of which publishes its own k to 2 k best: one workgroup per query walking all
+// 200 k places six times took longer than the scan itself (0.85 ms against 0.54 ms for one query over 1M rows).
+// Groups of 16 strips are merged by a workgroup each, then the groups' lists by one: 0.85 -> 0.1 ms.
+int merge_group(int n_strips) {
+    if (getenv("RAG_DENSE_MERGE_FLAT") || n_strips < 64) return 0;
+    return n_strips % 16 == 0 ? 16 : 8;                 // n_strips is a multiple of 8
+}
+
 // Geometry of a scan (query blocks, row strips) for p.n_queries / p.n_rows / p.k / p.cap, and the handle's work
 // buffers grown to hold it.  No launch: rag_dense_reserve runs this alone.
 template <int WQ, int TQ, int WR, int TR>
@@ -975,6 +988,12 @@ int plan_scan(rag_dense_t h, DenseScanParams& p) {
     if (rc) return rc;
     rc = h->cand_count.ensure((size_t)p.n_queries * p.n_strips * sizeof(int32_t));
     if (rc) return rc;
+    if (const int g = merge_group(p.n_strips)) {
+        const size_t n = (size_t)p.n_queries * (p.n_strips / g);
+        if ((rc = h->grp_score.ensure(n * p.k * sizeof(float)))) return rc;
+        if ((rc = h->grp_row.ensure(n * p.k * sizeof(int64_t)))) return rc;
+        if ((rc = h->grp_count.ensure(n * sizeof(int32_t)))) return rc;
+    }
     return h->tau_shared.ensure((size_t)p.n_queries * sizeof(uint32_t));
 }
 
@@ -1035,6 +1054,28 @@ int launch_scan(rag_dense_t h, DenseScanParams& p, hipStream_t stream, bool pres
     RAG_HIP_TRY(hipGetLastError());
     h->last_strips = p.n_strips;
     h->last_qblocks = p.n_qblocks;
+    return RAG_OK;
+}
+
+// The k best of every query's per-strip lists, sorted: in one level, or groups of strips first (merge_group).
+int merge_strips(rag_dense_t h, const DenseScanParams& p, int n_queries, int k, float* out_score, int64_t* out_row,
+                 int32_t* out_count, hipStream_t stream) {
+    const int g = merge_group(p.n_strips);
+    if (g == 0)
+        return launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, p.kpub, k, h->row_base, out_score, out_row,
+                                   out_count, p.fault, stream);
+    // (query, group) pairs are consecutive runs of g lists: the one-level kernel on n_queries * groups "queries"
+    const int groups = p.n_strips / g;
+    float* g_score = (float*)h->grp_score.p;
+    int64_t* g_row = (int64_t*)h->grp_row.p;
+    int32_t* g_count = (int32_t*)h->grp_count.p;
+    int rc = launch_merge_cand32(p.cand, p.cand_count, n_queries * groups, g, p.kpub, k, h->row_base, g_score, g_row,
+                                 g_count, p.fault, stream);
+    if (rc) return rc;
+    ragmerge::ListF32Src src{g_score, g_row, g_count, groups, k, 0};
+    hipLaunchKernelGGL(ragmerge::merge_topk_kernel<ragmerge::ListF32Src>, dim3(n_queries), dim3(ragmerge::MERGE_NT), 0,
+                       stream, src, k, (int64_t)0, 0, out_score, out_row, out_count, p.fault);
+    RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
@@ -1135,8 +1176,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         float* t_score = (float*)h->tmp_score.p;
         int64_t* t_row = (int64_t*)h->tmp_row.p;
         int32_t* t_count = (int32_t*)h->tmp_count.p;
-        rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, p.kpub, k, h->row_base, t_score, t_row,
-                                 t_count, p.fault, stream);
+        rc = merge_strips(h, p, n_queries, k, t_score, t_row, t_count, stream);
         if (rc) return rc;
         dense_rescore_kernel<<<(unsigned)ceil_div64((int64_t)nk, 4), 256, 0, stream>>>(
             h->rows, d_queries, t_row, t_score, (int64_t)nk, k, h->dim, h->row_base, h->n_rows, p.euclid);
@@ -1147,8 +1187,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
         RAG_HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    rc = launch_merge_cand32(p.cand, p.cand_count, n_queries, p.n_strips, p.kpub, k, h->row_base, d_out_score,
-                             d_out_row, d_out_count, p.fault, stream);
+    rc = merge_strips(h, p, n_queries, k, d_out_score, d_out_row, d_out_count, stream);
     if (rc) return rc;
     if (p.euclid) {
         euclid_finish_kernel<<<n_queries, 64, 0, stream>>>(d_out_score, d_out_count, d_queries, n_queries, k, h->dim);
