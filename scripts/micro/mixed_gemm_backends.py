@@ -30,7 +30,7 @@ def main():
         x = (torch.randn((m, 1152), generator=g, device=dev) * 0.5).half()
         w = (torch.randn((n, 1152), generator=g, device=dev) * 0.05).half()
         flops = 2.0 * m * 1152 * n
-        for lib in ('hipblaslt', 'cublas'):
+        for lib in ('hipblaslt', 'cublas', 'ck'):
             try:
                 torch.backends.cuda.preferred_blas_library(lib)
                 ms = timed(lambda: torch.mm(x, w.t(), out_dtype=torch.float32))
