@@ -580,7 +580,29 @@ def main():
         t1 = time.perf_counter()
         ids_t, len_t, voc_t = rag_hip.bm25_tokenize(texts, np.zeros(n_txt, np.uint8))
         t_tok = time.perf_counter() - t1
+        # the embedding side of the build: chunk texts of this shard through the bi-encoder (unpadded token streams,
+        # the path MedicalEmbedder.encode takes on the GPU), as VectorIndexer.index_chunks does for every chunk
+        n_emb = 16384
+        e_off = off[:n_emb + 1].to(torch.int64)
+        e_len = (e_off[1:] - e_off[:-1]).to(torch.int32)
+        e_ids = tok[:int(e_off[-1])].contiguous()
+        e_cu = torch.zeros((n_emb + 1,), dtype=torch.int32, device=dev)
+        e_cu[1:] = torch.cumsum(e_len, 0)
+        e_pos = (torch.arange(e_ids.shape[0], device=dev, dtype=torch.int32)
+                 - torch.repeat_interleave(e_cu[:-1], e_len.long()))
+        e_types = torch.zeros_like(e_ids)
+        longest = int(e_len.max())
+        with torch.no_grad():
+            bi.forward_packed(e_ids, e_types, e_pos, e_cu, longest, normalize=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bi.forward_packed(e_ids, e_types, e_pos, e_cu, longest, normalize=True)
+            torch.cuda.synchronize()
+        t_emb = time.perf_counter() - t1
         extra['index_build'] = {
+            'embed_chunks_per_s': round(n_emb / t_emb, 1), 'embed_tokens_per_s': round(int(e_ids.shape[0]) / t_emb, 1),
+            'embed_sample': '%d chunks, %d tokens, %s forward (fp32, split-bf16 GEMMs) + mean pooling + L2 norm in one '
+                            'unpadded batch' % (n_emb, int(e_ids.shape[0]), args.embed_arch),
             'bm25_postings_build_s': round(t_csr, 3), 'documents': int(host['ln'].shape[0]), 'tokens': int(host['term'].shape[0]),
             'postings': int(arr2.rows.shape[0]),
             'note': 'term-id stream -> term-major CSR + fp64 impacts on the device (rag_bm25_build_dev, rag_bm25_impacts_dev), '
