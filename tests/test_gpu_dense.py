@@ -145,6 +145,31 @@ def test_dense_wide_batches_take_the_same_rows_on_every_path(monkeypatch):
     _check(corpus[:100], queries[:256], 7)
 
 
+@pytest.mark.parametrize('b,k', [(1, 100), (20, 10), (64, 100), (130, 37)])
+def test_dense_two_level_strip_merge_equals_the_flat_merge(monkeypatch, b, k):
+    """Small batches are scanned in many row strips; their lists are merged in groups of strips first and then
+    across groups.  RAG_DENSE_MERGE_FLAT=1 merges every strip of a query in one go: same lists, bit for bit, in
+    both forms of the scan, with a row mask and for distances."""
+    import rag_hip
+    n, dim = 150_000, 64
+    corpus = synth.dense_corpus(n, dim, seed=41, dup_frac=0.01)
+    queries = synth.dense_queries(corpus, b, seed=42)
+    rng = np.random.default_rng(2)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    for metric in ('cosine', 'euclidean'):
+        idx = rag_hip.DenseIndex(corpus, metric=metric)
+        for split in (True, False):
+            idx.set_split(split)
+            for m in (None, mask):
+                two = idx.search(queries, k, row_mask=m)
+                monkeypatch.setenv('RAG_DENSE_MERGE_FLAT', '1')
+                flat = idx.search(queries, k, row_mask=m)
+                monkeypatch.delenv('RAG_DENSE_MERGE_FLAT')
+                for x, y in zip(two, flat):
+                    assert np.array_equal(x, y), (metric, split, m is not None)
+        idx.close()
+
+
 def test_dense_rescore_matches_scores():
     import rag_hip
     corpus = synth.dense_corpus(2000, 768, seed=8)
