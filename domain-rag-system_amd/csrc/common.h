@@ -79,6 +79,16 @@ int rag_grant_dyn_lds(const void* kernel, size_t bytes);
 // of making the access.
 uint32_t* rag_fault_word();
 
+// a stream under graph capture records no timing events (an event recorded into a graph cannot be read back)
+static inline bool rag_stream_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 // Once per device, with that device current: look up the device address of the static work array behind
 // rag_bm25_search_static_dev (bm25.hip).  Called by rag_init.
 int rag_bm25_static_setup();

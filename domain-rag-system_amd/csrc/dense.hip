@@ -1143,7 +1143,7 @@ extern "C" int rag_dense_search_dev(rag_dense_t h, const float* d_queries, int32
     // top-K: the threshold is reached by K real rows.
     const int64_t sample = prepass_rows(k);
     // timing aid: one event pair around everything the scan does (pre-pass included), not the final merge
-    const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING;
+    const bool prof = h->profiling && h->prof_n < rag_dense_s::PROF_RING && !rag_stream_capturing(stream);
     if (prof) RAG_HIP_TRY(hipEventRecord(h->ev0[h->prof_n], stream));
     const bool prepass = n_queries >= 128 && h->n_rows >= 16 * sample && !getenv("RAG_DENSE_NO_PREPASS");
     if (prepass) {

@@ -710,7 +710,7 @@ int launch_mlp(const MlpParams& p, int mode, hipStream_t stream, const char* who
     else if (mode == 2) RAG_GRANT_LDS(mlp_fused_kernel<2>, max_lds);
     else RAG_GRANT_LDS(mlp_fused_kernel<0>, max_lds);
     const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
-    const bool timed = g_prof.on && g_prof.n < MlpProfile::RING;
+    const bool timed = g_prof.on && g_prof.n < MlpProfile::RING && !rag_stream_capturing(stream);
     if (timed) RAG_HIP_TRY(hipEventRecord(g_prof.ev0[g_prof.n], stream));
     if (mode == 1)
         hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(ML_NT), lds_bytes, stream, p);

@@ -583,7 +583,7 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
     const size_t lds = (size_t)FS_OFF_B1 + 4 * ((size_t)k + 3 * FS_HID);
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)ceil_div64(m, FS_BM));
-    const bool timed = g_fs_prof.on && g_fs_prof.n < FsProfile::RING;
+    const bool timed = g_fs_prof.on && g_fs_prof.n < FsProfile::RING && !rag_stream_capturing(stream);
     if (timed) RAG_HIP_TRY(hipEventRecord(g_fs_prof.ev0[g_fs_prof.n], stream));
     if (in_is_split) {
         RAG_GRANT_LDS(ffn_out_split_kernel<1>, lds);

@@ -47,6 +47,53 @@ class TokenStore:
         self.tok, self.off, self.row_base = tok.contiguous(), off.contiguous(), int(row_base)
 
 
+class _Graphed:
+    """fn(*inputs) -> tensor, captured once in a HIP graph and replayed: for the launch-bound encoder forwards of very
+    small batches (a single query is ~100 launches of the bi-encoder and ~60 of the cross-encoder, each of them a few
+    microseconds of GPU work behind 10-20 of host work).  Shapes are static: inputs are copied into the captured
+    buffers, the result is the captured output buffer (valid until the next call).  Everything fn launches must be
+    capturable: no host synchronisation, no allocation outside PyTorch's allocator (the librag_hip entry points it
+    uses only launch kernels; work buffers and per-device LDS grants are settled by the warm-up calls)."""
+
+    def __init__(self, fn, inputs):
+        self.fn = fn                                      # keeps alive whatever the captured kernels read through it
+        self.inputs = [t.clone() for t in inputs]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                fn(*self.inputs)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = fn(*self.inputs)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+def pack_static(input_ids, attention_mask):
+    """BertEncoder.pack without a host round trip and with static shapes: padded [B, S] ids + left-aligned mask ->
+    (ids, types, pos int32 [B * S], cu_seqlens int32 [B + 1]); the stream's unused tail holds token 0 at position 0."""
+    b, s = input_ids.shape
+    dev = input_ids.device
+    t = b * s
+    keep = attention_mask.bool()
+    cu = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(keep.sum(dim=1), 0)
+    col = torch.arange(s, device=dev, dtype=torch.int64)
+    dest = torch.where(keep, cu[:-1, None].long() + col[None, :], torch.full((), t, dtype=torch.int64, device=dev))
+    flat = dest.reshape(-1)
+    ids = torch.zeros((t + 1,), dtype=torch.int32, device=dev).scatter_(0, flat, input_ids.reshape(-1).to(torch.int32))
+    pos = torch.zeros((t + 1,), dtype=torch.int32, device=dev).scatter_(0, flat, col.to(torch.int32).repeat(b))
+    return ids[:t], torch.zeros((t,), dtype=torch.int32, device=dev), pos[:t], cu
+
+
 class BatchSearcher:
     def __init__(self, dense: Optional[rag_hip.DenseIndex], bm25: Optional[rag_hip.Bm25Index],
                  canon: Optional[torch.Tensor] = None, bi_encoder=None, cross_encoder=None,
@@ -96,6 +143,9 @@ class BatchSearcher:
         # themselves when they collect results)
         self.check_faults = hasattr(rag_hip, 'check_faults')
         self._side_stream = None
+        # HIP graphs for the two encoder forwards of very small batches (RAG_GRAPHS=0 switches them off)
+        self.graph_max_batch = 0 if os.environ.get('RAG_GRAPHS') == '0' else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '2'))
+        self._graphs = {}
 
     # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
     @property
@@ -158,7 +208,39 @@ class BatchSearcher:
         else:
             self.dist.all_reduce(t)
 
+    def _graph_ok(self, b, dev):
+        return (0 < b <= self.graph_max_batch and dev.type == 'cuda' and not self.sharded
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _graphed(self, key, fn, inputs):
+        """The captured form of fn for this key (shapes), or None when capture failed once (then never tried again)."""
+        g = self._graphs.get(key)
+        if g is None and key not in self._graphs:
+            try:
+                g = _Graphed(fn, inputs)
+            except Exception as e:                       # noqa: BLE001 - any capture problem: run eagerly from now on
+                import warnings
+                warnings.warn(f"HIP graph capture of {key[0]} failed ({type(e).__name__}: {e}); running it eagerly")
+                torch.cuda.synchronize()
+                g = None
+            self._graphs[key] = g
+        return g
+
     def _embed_local(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        bert = self.bi_encoder.bert
+        if (getattr(bert, 'native', False) and self._graph_ok(ids.shape[0], ids.device)
+                and bert.word.weight.dtype == torch.float32 and getattr(bert, 'split_gemm', False)):
+            s = (ids.shape[1] + 31) // 32 * 32           # one graph per 32 columns of padded width
+            if s != ids.shape[1]:
+                ids = torch.nn.functional.pad(ids, (0, s - ids.shape[1]))
+                mask = torch.nn.functional.pad(mask, (0, s - mask.shape[1]))
+
+            def fwd(i, m):
+                p_ids, p_types, p_pos, cu = pack_static(i, m)
+                return self.bi_encoder.forward_packed(p_ids, p_types, p_pos, cu, s, normalize=True)
+            g = self._graphed(('embed', ids.shape[0], s, ids.dtype, mask.dtype), fwd, [ids, mask])
+            if g is not None:
+                return g(ids, mask).clone()
         if getattr(self.bi_encoder.bert, 'native', False):
             # unpadded: queries differ a lot in length, and padding positions cost full GEMM rows
             p_ids, p_types, p_pos, cu, longest = self.bi_encoder.bert.pack(ids, mask)
@@ -218,7 +300,9 @@ class BatchSearcher:
         logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
-            if self.ce_packed:
+            if self.ce_packed and self._graph_ok(b, dev) and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine):
+                pass
+            elif self.ce_packed:
                 self._ce_packed(q_tok, q_off, my_q, my_r, plen, logits_mine)
             else:
                 self._ce_padded(q_tok, q_off, my_q, my_r, plen, logits_mine)
@@ -239,6 +323,41 @@ class BatchSearcher:
             flat = logits[keep].contiguous()
         idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
         return idx, cnt, logits
+
+    def _ce_graphed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+        """Packing and the cross-encoder forward of a very small batch as one captured HIP graph.  Static shapes, chosen
+        from the batch's pair lengths (one small read-back, as the eager route has): the token stream in steps of 2048
+        tokens, the longest pair in steps of 64, the query tokens in steps of 64 per query; sequences are run at their
+        real lengths inside these.  Returns False when capture is unavailable (the caller then takes the eager route)."""
+        store = self.chunk_tokens
+        n = my_r.shape[0]
+        b = q_off.shape[0] - 1
+        cb = self.cross_encoder.bert
+        if not (cb.word.weight.dtype == torch.float32 and getattr(cb, 'split_gemm', False)):
+            return False
+        total, longest = (int(v) for v in torch.stack([plen.sum(), plen.max()]).cpu().tolist())
+        if longest <= 0:
+            return False
+        t_pad = (total + 2047) // 2048 * 2048
+        max_len = min(self.ce_max_len, (longest + 63) // 64 * 64)
+        q_cap = (max(int(q_tok.shape[0]), 1) + 64 * b - 1) // (64 * b) * (64 * b)
+        pair_query = my_q
+        cut = self.ce_max_len                                # pairs are truncated at the searcher's limit, as always
+
+        def fwd(qt, qo, rows):
+            lens = rag_hip.ce_pair_len_dev(qo, store.off, store.row_base, pair_query, rows, cut)
+            cu = torch.zeros((n + 1,), dtype=torch.int32, device=rows.device)
+            cu[1:] = torch.cumsum(lens, 0)
+            ids, types, pos = rag_hip.ce_pack_packed_dev(qt, qo, store.tok, store.off, store.row_base, pair_query, rows, cu,
+                                                         t_pad, cut, self.cls_id, self.sep_id, padded_total=t_pad)
+            return self.cross_encoder.forward_packed(ids, types, pos, cu, max_len)
+        qt = torch.zeros((q_cap,), dtype=torch.int32, device=q_tok.device)
+        qt[:q_tok.shape[0]] = q_tok
+        g = self._graphed(('rerank', b, n, t_pad, max_len, q_cap, id(store)), fwd, [qt, q_off, my_r])
+        if g is None:
+            return False
+        logits_mine[:n] = g(qt, q_off, my_r)
+        return True
 
     def _ce_padded(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
         """Pairs sorted by length, padded mini-batches (any model dtype, PyTorch or native ops)."""

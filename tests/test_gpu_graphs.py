@@ -1,0 +1,88 @@
+"""GPU: the encoder forwards of very small batches replayed from HIP graphs (BatchSearcher, RAG_GRAPHS) give the
+answers of the eager path: same embeddings, same fused lists, same logits, same final rows, for several batches
+in a row through the same captured graphs, with queries of different lengths."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _world(dev):
+    import rag_hip
+    from indexing import bert
+    from indexing.bm25_indexer import build_arrays
+    n, dim, vocab = 30000, 768, 2000
+    corpus = synth.dense_corpus(n, dim, seed=51)
+    term, doc, ln = synth.sparse_corpus(n, vocab, seed=52, mean_len=25)
+    arr = build_arrays(term, doc, ln, vocab, 1.5, 0.75)
+    dense = rag_hip.DenseIndex(corpus)
+    bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n)
+    bi, _, _ = bert.load_model('random:bert-base', 'bi', dev, native=True, split_gemm=True)
+    ce, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                               split_dtype=torch.float16)
+    rng = np.random.default_rng(53)
+    clen = ln + 2
+    off = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+    tok = rng.integers(1000, 30522, size=int(off[-1])).astype(np.int32)
+    return dict(dense=dense, bm25=bm25, bi=bi, ce=ce, tok=torch.from_numpy(tok).to(dev), off=torch.from_numpy(off).to(dev),
+                term=term, doc=doc, ln=ln, vocab=vocab)
+
+
+def _queries(w, b, seed, dev):
+    import rag_hip
+    rng = np.random.default_rng(seed)
+    qlen = rng.integers(5, 40, size=b)
+    smax = int(qlen.max()) + 2
+    ids = np.zeros((b, smax), np.int64)
+    mask = np.zeros((b, smax), np.int64)
+    ce_tok, ce_off = [], [0]
+    for i in range(b):
+        body = rng.integers(1000, 30522, size=int(qlen[i]))
+        ids[i, 0], ids[i, 1:1 + qlen[i]], ids[i, 1 + qlen[i]] = 101, body, 102
+        mask[i, :qlen[i] + 2] = 1
+        ce_tok.append(body)
+        ce_off.append(ce_off[-1] + int(qlen[i]))
+    qterms, qoff = rag_hip.Bm25Index.flatten(synth.sparse_queries(w['term'], w['doc'], w['ln'], w['vocab'], b, seed=seed + 1))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return (t(ids), t(mask), t(qterms), t(qoff), int(qoff[-1]), t(np.concatenate(ce_tok).astype(np.int32)),
+            t(np.asarray(ce_off, np.int64)))
+
+
+@pytest.mark.parametrize('b', [1, 2])
+def test_graph_replay_equals_the_eager_path(b, monkeypatch):
+    from indexing.batch import BatchSearcher, TokenStore, pack_static
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    w = _world(dev)
+    mk = lambda: BatchSearcher(w['dense'], w['bm25'], bi_encoder=w['bi'], cross_encoder=w['ce'],
+                               chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=20)
+    graphed = mk()
+    monkeypatch.setenv('RAG_GRAPHS', '0')
+    eager = mk()
+    monkeypatch.delenv('RAG_GRAPHS')
+    assert graphed.graph_max_batch >= 2 and eager.graph_max_batch == 0
+    for seed in (1, 2, 3, 4):
+        q = _queries(w, b, 100 * b + seed, dev)
+        a = graphed.search(*q)
+        e = eager.search(*q)
+        torch.cuda.synchronize()
+        assert torch.equal(a['fused_row'], e['fused_row']) and torch.equal(a['fused_score'], e['fused_score'])
+        assert float((a['logits'] - e['logits']).abs().max()) < 2e-6        # same kernels on the same rows of a longer stream
+        assert torch.equal(a['rows'], e['rows']) and torch.equal(a['count'], e['count'])
+    # both forwards really came from captured graphs, one per shape
+    kinds = sorted(k[0] for k, g in graphed._graphs.items() if g is not None)
+    assert 'embed' in kinds and 'rerank' in kinds
+    assert not eager._graphs
+    # the static packing is the boolean-mask packing
+    ids, mask = q[0], q[1]
+    p_ids, p_types, p_pos, cu, longest = w['bi'].bert.pack(ids, mask)
+    s_ids, s_types, s_pos, s_cu = pack_static(ids, mask)
+    n = int(cu[-1])
+    assert torch.equal(cu, s_cu) and torch.equal(p_ids, s_ids[:n]) and torch.equal(p_pos, s_pos[:n])
+    assert int(s_ids[n:].abs().sum()) == 0
+    w['dense'].close()
+    w['bm25'].close()
