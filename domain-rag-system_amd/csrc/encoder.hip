@@ -456,12 +456,14 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                s[i] = exp2f(s[i] - m_new);
+                // the bare v_exp_f32: arguments are <= 0, and below -126 the result is as good as zero either way
+                // (exp2f() wraps every call in a five-instruction range extension, a third of this loop's vector work)
+                s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
                 sum += s[i];
             }
             sum += __shfl_xor(sum, 32, 64);
             if (kb > 0) {
-                const float alpha = exp2f(m_run - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run = l_run * alpha + sum;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
