@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 import rag_hip
+from .bert import Graphed as _Graphed
 
 
 @dataclass
@@ -45,36 +46,6 @@ class TokenStore:
     def __init__(self, tok: torch.Tensor, off: torch.Tensor, row_base: int = 0):
         assert tok.dtype == torch.int32 and off.dtype == torch.int64
         self.tok, self.off, self.row_base = tok.contiguous(), off.contiguous(), int(row_base)
-
-
-class _Graphed:
-    """fn(*inputs) -> tensor, captured once in a HIP graph and replayed: for the launch-bound encoder forwards of very
-    small batches (a single query is ~100 launches of the bi-encoder and ~60 of the cross-encoder, each of them a few
-    microseconds of GPU work behind 10-20 of host work).  Shapes are static: inputs are copied into the captured
-    buffers, the result is the captured output buffer (valid until the next call).  Everything fn launches must be
-    capturable: no host synchronisation, no allocation outside PyTorch's allocator (the librag_hip entry points it
-    uses only launch kernels; work buffers and per-device LDS grants are settled by the warm-up calls)."""
-
-    def __init__(self, fn, inputs):
-        self.fn = fn                                      # keeps alive whatever the captured kernels read through it
-        self.inputs = [t.clone() for t in inputs]
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                fn(*self.inputs)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.out = fn(*self.inputs)
-
-    def __call__(self, *inputs):
-        for dst, src in zip(self.inputs, inputs):
-            dst.copy_(src, non_blocking=True)
-        self.graph.replay()
-        return self.out
 
 
 def pack_static(input_ids, attention_mask):

@@ -323,6 +323,86 @@ class BertEncoder(nn.Module):
         return y.add_(module.bias)
 
 
+class Graphed:
+    """fn(*inputs) -> tensor, captured once in a HIP graph and replayed: for the launch-bound encoder forwards of very
+    small batches (a single query is ~100 launches of the bi-encoder and ~45 of the cross-encoder, each of them a few
+    microseconds of GPU work behind 10-20 of host work).  Shapes are static: inputs are copied into the captured
+    buffers, the result is the captured output buffer (valid until the next call).  Everything fn launches must be
+    capturable: no host synchronisation, no allocation outside PyTorch's allocator (the librag_hip entry points it
+    uses only launch kernels; work buffers and per-device LDS grants are settled by the warm-up calls)."""
+
+    def __init__(self, fn, inputs):
+        self.fn = fn                                      # keeps alive whatever the captured kernels read through it
+        self.inputs = [t.clone() for t in inputs]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                fn(*self.inputs)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = fn(*self.inputs)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+class GraphCache:
+    """Captured graphs by shape key, at most `limit` of them (the oldest is dropped); a key whose capture failed
+    once is remembered and never tried again."""
+
+    def __init__(self, limit=32):
+        self.limit = limit
+        self.graphs = {}
+
+    def get(self, key, fn, inputs):
+        if key in self.graphs:
+            return self.graphs[key]
+        if os.environ.get('RAG_GRAPHS') == '0' or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return None
+        try:
+            g = Graphed(fn, inputs)
+        except Exception as e:                            # noqa: BLE001 - any capture problem: run eagerly from now on
+            import warnings
+            warnings.warn(f"HIP graph capture of {key[0]} failed ({type(e).__name__}: {e}); running it eagerly")
+            torch.cuda.synchronize()
+            g = None
+        while len(self.graphs) >= self.limit:
+            self.graphs.pop(next(iter(self.graphs)))
+        self.graphs[key] = g
+        return g
+
+
+def forward_packed_graphed(model, cache, ids, types, pos, cu, longest, **kw):
+    """model.forward_packed(ids, types, pos, cu, longest, **kw) replayed from a HIP graph: the token stream is padded
+    to a step of 256 tokens (2048 beyond 4096) and the longest sequence to a step of 64, the sequences themselves run
+    at their real lengths.  Returns None when no graph is available (the caller then calls forward_packed)."""
+    t = int(ids.shape[0])
+    step = 256 if t <= 4096 else 2048
+    t_pad = (t + step) // step * step                     # at least one token beyond the stream
+    max_len = (int(longest) + 63) // 64 * 64
+    n_seq = int(cu.shape[0]) - 1
+
+    def fwd(i, ty, p, c):
+        return model.forward_packed(i, ty, p, c, max_len, **kw)
+
+    def padded(x):
+        out = torch.zeros((t_pad,), dtype=torch.int32, device=x.device)
+        out[:t] = x
+        return out
+    inputs = [padded(ids), padded(types), padded(pos), cu]
+    g = cache.get((type(model).__name__, n_seq, t_pad, max_len, tuple(sorted(kw.items()))), fwd, inputs)
+    if g is None:
+        return None
+    return g(*inputs).clone()
+
+
 class BiEncoder(nn.Module):
     """BERT -> mean pooling over real tokens -> (optional) L2 normalisation."""
 

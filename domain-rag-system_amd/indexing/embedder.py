@@ -37,6 +37,9 @@ class MedicalEmbedder:
                                                           split_gemm=split_gemm and dtype == torch.float32)
         self.max_length = min(max_length, cfg.max_position_embeddings)
         self.embedding_dim = cfg.hidden_size
+        self._graphs = bert.GraphCache()          # HIP graphs of the forward for one or two texts (a query at a time)
+        self._recent = {}                         # embeddings of the last few single texts (a query is embedded for
+        #                                           the search and again by the simple reranker)
 
     def tokenize(self, text: str) -> List[int]:
         """[CLS] tokens [SEP], truncated to ``max_length``."""
@@ -73,17 +76,34 @@ class MedicalEmbedder:
             cu = (cu_all[p0:p1 + 1] - cu_all[p0]).astype(np.int32)
             dev = self.device
             ids_t = torch.from_numpy(flat).to(dev)
-            emb = self.model.forward_packed(ids_t, torch.zeros_like(ids_t), torch.from_numpy(pos).to(dev),
-                                            torch.from_numpy(cu).to(dev), max(int(lens[p0:p1].max()), 1), normalize=normalize)
+            longest = max(int(lens[p0:p1].max()), 1)
+            emb = None
+            if p1 - p0 <= 2 and flat.size <= 1024 and self.model.bert.split_gemm:
+                # a query at a time is launch bound: replay the forward from a HIP graph
+                emb = bert.forward_packed_graphed(self.model, self._graphs, ids_t, torch.zeros_like(ids_t),
+                                                  torch.from_numpy(pos).to(dev), torch.from_numpy(cu).to(dev), longest,
+                                                  normalize=normalize)
+            if emb is None:
+                emb = self.model.forward_packed(ids_t, torch.zeros_like(ids_t), torch.from_numpy(pos).to(dev),
+                                                torch.from_numpy(cu).to(dev), longest, normalize=normalize)
             out[p0:p1] = emb
             p0 = p1
         return out
 
     def encode(self, texts: Union[str, List[str]], normalize: bool = True) -> np.ndarray:
-        if isinstance(texts, str):
+        single = isinstance(texts, str)
+        if single:
+            hit = self._recent.get((texts, bool(normalize)))
+            if hit is not None:
+                return hit.copy()
             texts = [texts]
         emb = self.encode_tokens([self.tokenize(t) for t in texts], normalize=normalize)
-        return np.ascontiguousarray(emb.cpu().numpy(), dtype=np.float32)
+        out = np.ascontiguousarray(emb.cpu().numpy(), dtype=np.float32)
+        if single:
+            if len(self._recent) >= 16:
+                self._recent.pop(next(iter(self._recent)))
+            self._recent[(texts[0], bool(normalize))] = out.copy()
+        return out
 
     def encode_chunks(self, chunks: List[Dict], text_key: str = 'text') -> np.ndarray:
         return self.encode([c[text_key] if isinstance(c, dict) else c.text for c in chunks])

@@ -130,6 +130,7 @@ class CrossEncoderReranker(BaseReranker):
                                                           split_dtype=torch.float16)
         self.batch_size = batch_size
         self.max_length = min(max_length, cfg.max_position_embeddings)
+        self._graphs = bert.GraphCache()          # HIP graphs of the forward for a query's pool
 
     def encode_pair(self, a: str, b: str):
         """[CLS] a [SEP] b [SEP]; the second text is cut so the pair fits ``max_length``."""
@@ -155,7 +156,13 @@ class CrossEncoderReranker(BaseReranker):
             ids = torch.tensor([t for e in enc for t in e[0]], dtype=torch.int32, device=dev)
             types = torch.tensor([t for e in enc for t in e[1]], dtype=torch.int32, device=dev)
             pos = torch.from_numpy(np.concatenate([np.arange(l, dtype=np.int32) for l in lens])).to(dev)
-            logits = self.model.forward_packed(ids, types, pos, torch.from_numpy(cu).to(dev), int(lens.max()))
+            cu_t = torch.from_numpy(cu).to(dev)
+            logits = None
+            if len(enc) <= 64 and ids.shape[0] <= 16384 and self.model.bert.split_gemm:
+                # one query's pool is launch bound: replay the forward from a HIP graph
+                logits = bert.forward_packed_graphed(self.model, self._graphs, ids, types, pos, cu_t, int(lens.max()))
+            if logits is None:
+                logits = self.model.forward_packed(ids, types, pos, cu_t, int(lens.max()))
             return [float(v) for v in logits.reshape(len(enc), -1)[:, 0].cpu().tolist()]
         order = sorted(range(len(enc)), key=lambda i: -len(enc[i][0]))
         out = [0.0] * len(enc)

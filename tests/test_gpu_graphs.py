@@ -86,3 +86,31 @@ def test_graph_replay_equals_the_eager_path(b, monkeypatch):
     assert int(s_ids[n:].abs().sum()) == 0
     w['dense'].close()
     w['bm25'].close()
+
+
+def test_class_api_single_calls_replay_graphs(monkeypatch):
+    """MedicalEmbedder.encode of one text and CrossEncoderReranker.score_pairs of one pool (what the reference's
+    query script calls per query) replay captured graphs: same embeddings and logits as the eager calls."""
+    from indexing import MedicalEmbedder
+    from reranker import CrossEncoderReranker
+    emb = MedicalEmbedder(model_name='random:bert-base', device='cuda')
+    ce = CrossEncoderReranker(model_name='random:minilm-l6', top_n=50, device='cuda')
+    rng = np.random.default_rng(7)
+    words = ['w%04d' % i for i in range(3000)]
+    text = lambda n: ' '.join(words[j] for j in rng.integers(0, len(words), size=n))
+    queries = [text(int(rng.integers(3, 20))) for _ in range(6)]
+    pools = [[text(int(rng.integers(10, 90))) for _ in range(50)] for _ in range(3)] + [[text(30) for _ in range(7)]]
+    got_e = [emb.encode(q) for q in queries] + [emb.encode(queries[0])]
+    got_l = [ce.score_pairs([(queries[i], t) for t in pool]) for i, pool in enumerate(pools)]
+    assert any(g is not None for g in emb._graphs.graphs.values())
+    assert any(g is not None for g in ce._graphs.graphs.values())
+    monkeypatch.setenv('RAG_GRAPHS', '0')
+    emb._graphs.graphs.clear()
+    ce._graphs.graphs.clear()
+    want_e = [emb.encode(q) for q in queries] + [emb.encode(queries[0])]
+    want_l = [ce.score_pairs([(queries[i], t) for t in pool]) for i, pool in enumerate(pools)]
+    assert not emb._graphs.graphs and not ce._graphs.graphs
+    for a, b in zip(got_e, want_e):
+        assert a.shape == b.shape == (1, 768) and float(np.abs(a - b).max()) < 1e-6
+    for a, b in zip(got_l, want_l):
+        assert len(a) == len(b) and float(np.abs(np.asarray(a) - np.asarray(b)).max()) < 2e-6
