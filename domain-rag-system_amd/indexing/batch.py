@@ -115,7 +115,11 @@ class BatchSearcher:
         self.check_faults = hasattr(rag_hip, 'check_faults')
         self._side_stream = None
         # HIP graphs for the two encoder forwards of very small batches (RAG_GRAPHS=0 switches them off)
-        self.graph_max_batch = 0 if os.environ.get('RAG_GRAPHS') == '0' else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '2'))
+        # (measured, 1M rows, 50 pairs per query: the embedder's graph wins up to 16 queries, 2.1 -> 0.9-1.3 ms; the
+        # cross-encoder's up to 4, beyond that its forward is no longer launch bound)
+        off = os.environ.get('RAG_GRAPHS') == '0'
+        self.graph_max_batch = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '16'))
+        self.graph_max_batch_ce = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH_CE', '4'))
         self._graphs = {}
 
     # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
@@ -179,8 +183,8 @@ class BatchSearcher:
         else:
             self.dist.all_reduce(t)
 
-    def _graph_ok(self, b, dev):
-        return (0 < b <= self.graph_max_batch and dev.type == 'cuda' and not self.sharded
+    def _graph_ok(self, b, dev, limit=None):
+        return (0 < b <= (self.graph_max_batch if limit is None else limit) and dev.type == 'cuda' and not self.sharded
                 and not torch.cuda.is_current_stream_capturing())
 
     def _graphed(self, key, fn, inputs):
@@ -271,7 +275,7 @@ class BatchSearcher:
         logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
-            if self.ce_packed and self._graph_ok(b, dev) and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine):
+            if self.ce_packed and self._graph_ok(b, dev, self.graph_max_batch_ce) and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine):
                 pass
             elif self.ce_packed:
                 self._ce_packed(q_tok, q_off, my_q, my_r, plen, logits_mine)

@@ -280,7 +280,10 @@ class BertEncoder(nn.Module):
         head_dim = self.config.hidden_size // self.config.num_attention_heads
         mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)
         c = self.config
-        fused_out = (self.fused_split_out
+        # (a 128-token tile of the fused output kernel takes ~100 us however empty the chip is: below ~96 tiles the
+        # library GEMM + tail kernels, which spread a small batch over the chip, are faster: 1.08 against 1.53 ms for
+        # one query's 50 pairs, equal at 14 k tokens, slower from there on)
+        fused_out = (self.fused_split_out and x.shape[0] >= int(os.environ.get('RAG_FUSED_OUT_MIN_TOKENS', '12288'))
                      and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, half)
                      and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, half))
         for li, l in enumerate(self.layers):

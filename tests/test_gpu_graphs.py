@@ -64,7 +64,7 @@ def test_graph_replay_equals_the_eager_path(b, monkeypatch):
     monkeypatch.setenv('RAG_GRAPHS', '0')
     eager = mk()
     monkeypatch.delenv('RAG_GRAPHS')
-    assert graphed.graph_max_batch >= 2 and eager.graph_max_batch == 0
+    assert graphed.graph_max_batch >= 2 and graphed.graph_max_batch_ce >= 2 and eager.graph_max_batch == 0
     for seed in (1, 2, 3, 4):
         q = _queries(w, b, 100 * b + seed, dev)
         a = graphed.search(*q)
