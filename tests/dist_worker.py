@@ -45,17 +45,22 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
     from indexing.batch import BatchSearcher, TokenStore
     from indexing.bm25_indexer import build_arrays
     dist = None
-    if world > 1:
+    force = os.environ.get('RAG_DIST_FORCE') == '1'      # single rank over RCCL: every exchange runs, each an identity
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        if force and world == 1 and device != 'cpu':
+            torch.cuda.set_device(0)
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
     w = make_world()
     n = w['corpus'].shape[0]
     lo, hi = n * rank // world, n * (rank + 1) // world
     sel = (w['doc'] >= lo) & (w['doc'] < hi)
     stats = None
-    if world > 1:
+    if world > 1 or force:
         df = np.bincount(np.unique(w['term'] * n + w['doc']) // n, minlength=w['v'])
         stats = dict(df=df, total_len=int(w['ln'].sum()), n_docs=n)
     arr = build_arrays(w['term'][sel], w['doc'][sel] - lo, w['ln'][lo:hi], w['v'], 1.5, 0.75, global_stats=stats)
@@ -79,7 +84,7 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
     s.split_embed = False                  # first every rank embeds every query ...
     out = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]),
                    ce_tok, ce_off)
-    if world > 1:
+    if world > 1 or force:
         # ... then the default: each rank embeds a slice and the slices are exchanged; same answer
         s.split_embed = True
         again = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]),

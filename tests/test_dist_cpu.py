@@ -19,10 +19,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, out_path, fusion, metric='cosine', reranker='cross', device='cpu'):
+def _run(world, out_path, fusion, metric='cosine', reranker='cross', device='cpu', env=None):
     port = _free_port()
+    full_env = dict(os.environ, **(env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
-                               out_path, fusion, metric, reranker, device]) for r in range(world)]
+                               out_path, fusion, metric, reranker, device], env=full_env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     return torch.load(out_path, weights_only=True)
@@ -71,3 +72,16 @@ def test_two_ranks_on_one_gpu_equal_one_with_the_real_kernels(tmp_path, reranker
     assert torch.equal(one['fused_score'], two['fused_score'])
     assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
     assert torch.allclose(one['rerank_score'], two['rerank_score'], atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('reranker', ['cross', 'simple'])
+def test_single_rank_over_rccl_takes_every_exchange(tmp_path, reranker):
+    """The RCCL branch of the exchanges (device tensors straight into the collectives) with one rank: RAG_DIST_FORCE=1
+    makes a world of one take every all-gather / all-reduce and merge (each an identity), on backend "nccl".  Same
+    answer as the run without a process group."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'cosine', reranker, 'cuda')
+    forced = _run(1, str(tmp_path / 'forced.pt'), 'rrf', 'cosine', reranker, 'cuda', env={'RAG_DIST_FORCE': '1'})
+    assert torch.equal(one['fused_row'], forced['fused_row']) and torch.equal(one['fused_score'], forced['fused_score'])
+    assert torch.equal(one['rows'], forced['rows']) and torch.equal(one['count'], forced['count'])
+    assert torch.allclose(one['rerank_score'], forced['rerank_score'], atol=1e-5)
