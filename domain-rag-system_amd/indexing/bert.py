@@ -106,6 +106,7 @@ class BertEncoder(nn.Module):
         self.fused_split_tails = True   # with split_gemm: one kernel for the work between two GEMMs
         self.split_attention = True     # with split_gemm: attention as split-precision MFMA products (rag_enc_attention_split_dev)
         self.split_dtype = torch.bfloat16   # 16-bit type of the split halves: bfloat16 (16 bits between them) or float16 (22)
+        self.trim_last_q = os.environ.get('RAG_TRIM_LAST_Q', '1') != '0'   # first_token_only: last layer projects queries for the first rows only
         self.fused_split_out = True     # fp16 halves, hidden 384: output projection / second feed-forward product with
         #                                 everything around them in one kernel (rag_enc_linear_ln_split_dev)
         self.native_linear = True    # bfloat16, hidden 384: q|k|v and output projections through rag_enc_linear384_dev
@@ -290,7 +291,18 @@ class BertEncoder(nn.Module):
             cls_only = first_token_only and li == last
             if mfma_attn:
                 # q|k|v bias inside the attention kernel; output already split for the next GEMM
-                ctx3 = rag_hip.enc_attention_split_dev(mm(xs, l.qkv), l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
+                if cls_only and self.trim_last_q and xs.shape[0] > 4 * (cu_seqlens.shape[0] - 1):
+                    # only the first row of every sequence is a query in this layer: keys and values for every token
+                    # (the GEMM writes the k|v columns of the usual [T, 3H] layout in place), queries for those rows
+                    w3 = self._split_weight(l.qkv)
+                    hdim = c.hidden_size
+                    qkv = torch.empty((xs.shape[0], 3 * hdim), dtype=torch.float32, device=xs.device)
+                    torch.mm(xs, w3[hdim:].t(), out_dtype=torch.float32, out=qkv[:, hdim:])
+                    first = cu_seqlens[:-1].long()
+                    qkv[first, :hdim] = torch.mm(xs[first], w3[:hdim].t(), out_dtype=torch.float32)
+                else:
+                    qkv = mm(xs, l.qkv)
+                ctx3 = rag_hip.enc_attention_split_dev(qkv, l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
                                                        first_only=cls_only, half=half)
             else:
                 qkv = mm(xs, l.qkv).add_(l.qkv.bias)
