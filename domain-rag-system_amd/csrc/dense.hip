@@ -1000,6 +1000,12 @@ int plan_scan(rag_dense_t h, DenseScanParams& p) {
 // which tile configuration a batch of n_queries runs
 template <typename F>
 int dense_dispatch(int n_queries, F&& f) {
+    if (const char* e = getenv("RAG_DENSE_CFG")) {          // tuning aid: force a tile configuration
+        const int c = atoi(e);
+        if (c == 0) return f(std::integral_constant<int, 0>{});
+        if (c == 1) return f(std::integral_constant<int, 1>{});
+        if (c == 2) return f(std::integral_constant<int, 2>{});
+    }
     if (n_queries <= 32) return f(std::integral_constant<int, 0>{});
     if (n_queries <= 64) return f(std::integral_constant<int, 1>{});
     if (getenv("RAG_DENSE_WIDE") || n_queries < 256) return f(std::integral_constant<int, 2>{});
