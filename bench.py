@@ -263,7 +263,19 @@ def main():
         if rehearse:
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one
+            # JSON line (file descriptor 1 points at stderr until the communicator exists)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     import rag_hip
