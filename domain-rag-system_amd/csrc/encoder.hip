@@ -846,14 +846,17 @@ __global__ __launch_bounds__(256) void bias_add_layernorm_split_kernel(const flo
 }
 
 // LayerNorm(word[id] + position[pos] + type[tt]) per token, one wave per token.
-template <typename T>
+// SPLIT (float tables only): also write the row as [hi | hi | lo] in that 16-bit type, the left operand of the
+// first split-precision GEMM (what split_bf16x3_kernel would make of the row in a pass of its own).
+template <typename T, typename SPLIT = bf16>
 __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __restrict__ ids,
                                                               const int32_t* __restrict__ types,
                                                               const int32_t* __restrict__ pos, const T* __restrict__ word,
                                                               const T* __restrict__ position, const T* __restrict__ type_emb,
                                                               const T* __restrict__ gamma, const T* __restrict__ beta,
                                                               float eps, int64_t n_tokens, int H, int vocab, int max_pos,
-                                                              int n_types, T* __restrict__ out, uint32_t* fault) {
+                                                              int n_types, T* __restrict__ out, uint32_t* fault,
+                                                              SPLIT* __restrict__ split = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tokens) return;
@@ -904,6 +907,19 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __r
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
             Vec8<T>::store(out + t * H + ch * 8, y);
+            if constexpr (std::is_same<T, float>::value) {
+                if (split != nullptr) {
+                    typename Half16<SPLIT>::x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        RAG_SPLIT_HI_LO(SPLIT, y[j], hi[j], lo[j]);
+                    }
+                    SPLIT* o = split + t * 3 * H + ch * 8;
+                    *reinterpret_cast<typename Half16<SPLIT>::x8*>(o) = hi;
+                    *reinterpret_cast<typename Half16<SPLIT>::x8*>(o + H) = hi;
+                    *reinterpret_cast<typename Half16<SPLIT>::x8*>(o + 2 * H) = lo;
+                }
+            }
         }
     }
 }
@@ -1053,15 +1069,17 @@ extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual
     return RAG_OK;
 }
 
-extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
-                                           const void* d_word, const void* d_position, const void* d_type_emb,
-                                           const void* d_gamma, const void* d_beta, float eps, int64_t n_tokens,
-                                           int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
-                                           int32_t dtype, void* d_out, void* stream_) {
+namespace {
+int embed_layernorm_launch(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos, const void* d_word,
+                           const void* d_position, const void* d_type_emb, const void* d_gamma, const void* d_beta, float eps,
+                           int64_t n_tokens, int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types, int32_t dtype,
+                           void* d_out, int32_t half_dtype, void* d_out_split, void* stream_) {
     RAG_REQUIRE(n_tokens >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
                 "rag_enc_embed_layernorm: hidden must be a multiple of 8 up to %d (got %d)", 8 * 64 * LN_MAX_CHUNKS, hidden);
     RAG_REQUIRE(vocab >= 1 && max_pos >= 1 && n_types >= 1, RAG_EINVAL, "rag_enc_embed_layernorm: empty table");
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_embed_layernorm: unknown dtype");
+    RAG_REQUIRE(d_out_split == nullptr || (dtype == RAG_DTYPE_F32 && (half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16)),
+                RAG_EINVAL, "rag_enc_embed_layernorm_split: fp32 tables and bf16 or fp16 halves");
     if (n_tokens == 0) return RAG_OK;
     RAG_REQUIRE(d_ids && d_pos && d_word && d_position && d_type_emb && d_gamma && d_beta && d_out, RAG_EINVAL,
                 "rag_enc_embed_layernorm: null pointer");
@@ -1074,14 +1092,38 @@ extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* 
                                                                (const bf16*)d_gamma, (const bf16*)d_beta, eps, n_tokens,
                                                                hidden, vocab, max_pos, n_types, (bf16*)d_out,
                                                                rag_fault_word());
+    else if (d_out_split != nullptr && half_dtype == RAG_DTYPE_F16)
+        embed_layernorm_kernel<float, _Float16><<<grid, 256, 0, stream>>>(
+            d_ids, d_types, d_pos, (const float*)d_word, (const float*)d_position, (const float*)d_type_emb,
+            (const float*)d_gamma, (const float*)d_beta, eps, n_tokens, hidden, vocab, max_pos, n_types, (float*)d_out,
+            rag_fault_word(), (_Float16*)d_out_split);
     else
-        embed_layernorm_kernel<float><<<grid, 256, 0, stream>>>(d_ids, d_types, d_pos, (const float*)d_word,
-                                                                (const float*)d_position, (const float*)d_type_emb,
-                                                                (const float*)d_gamma, (const float*)d_beta, eps,
-                                                                n_tokens, hidden, vocab, max_pos, n_types,
-                                                                (float*)d_out, rag_fault_word());
+        embed_layernorm_kernel<float, bf16><<<grid, 256, 0, stream>>>(
+            d_ids, d_types, d_pos, (const float*)d_word, (const float*)d_position, (const float*)d_type_emb,
+            (const float*)d_gamma, (const float*)d_beta, eps, n_tokens, hidden, vocab, max_pos, n_types, (float*)d_out,
+            rag_fault_word(), (bf16*)d_out_split);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
+                                           const void* d_word, const void* d_position, const void* d_type_emb,
+                                           const void* d_gamma, const void* d_beta, float eps, int64_t n_tokens,
+                                           int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
+                                           int32_t dtype, void* d_out, void* stream_) {
+    return embed_layernorm_launch(d_ids, d_types, d_pos, d_word, d_position, d_type_emb, d_gamma, d_beta, eps, n_tokens,
+                                  hidden, vocab, max_pos, n_types, dtype, d_out, 0, nullptr, stream_);
+}
+
+extern "C" int rag_enc_embed_layernorm_split_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
+                                                 const float* d_word, const float* d_position, const float* d_type_emb,
+                                                 const float* d_gamma, const float* d_beta, float eps, int64_t n_tokens,
+                                                 int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
+                                                 float* d_out, int32_t half_dtype, void* d_out_split, void* stream_) {
+    RAG_REQUIRE(d_out_split != nullptr || n_tokens == 0, RAG_EINVAL, "rag_enc_embed_layernorm_split: null split output");
+    return embed_layernorm_launch(d_ids, d_types, d_pos, d_word, d_position, d_type_emb, d_gamma, d_beta, eps, n_tokens,
+                                  hidden, vocab, max_pos, n_types, RAG_DTYPE_F32, d_out, half_dtype, d_out_split, stream_);
 }
 
 namespace {

@@ -169,11 +169,15 @@ class BertEncoder(nn.Module):
                                                max_seq_len):
             raise ValueError("the packed encoder path needs bfloat16 or float32 weights, head size 32 or 64 and "
                              f"sequences up to {rag_hip.ENC_MAX_SEQ} tokens")
+        if self.split_gemm and self.fused_split_tails and self.word.weight.dtype == torch.float32:
+            # embedding + LayerNorm + the split for the first GEMM in one pass
+            x, xs = rag_hip.enc_embed_layernorm_split_dev(ids, types, pos, self.word.weight, self.position.weight,
+                                                          self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
+                                                          self.emb_norm.eps, self.split_dtype)
+            return self._forward_packed_split(x, cu_seqlens, max_seq_len, first_token_only, xs)
         x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
                                             self.emb_norm.eps)
-        if self.split_gemm and self.fused_split_tails and x.dtype == torch.float32:
-            return self._forward_packed_split(x, cu_seqlens, max_seq_len, first_token_only)
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
         for li, l in enumerate(self.layers):
@@ -265,7 +269,7 @@ class BertEncoder(nn.Module):
             self._split_cache[key] = w
         return w
 
-    def _forward_packed_split(self, x, cu_seqlens, max_seq_len, first_token_only=False):
+    def _forward_packed_split(self, x, cu_seqlens, max_seq_len, first_token_only=False, xs=None):
         """The fp32 layers with every GEMM as a split-bf16 product (see _linear_split) and the work between
         two GEMMs in one kernel each: bias + residual + LayerNorm + split of the result, bias + GELU + split.
         Same arithmetic in the same order as the separate kernels, so the same hidden states bit for bit.
@@ -276,7 +280,8 @@ class BertEncoder(nn.Module):
         import rag_hip
         mm = lambda a3, module: torch.mm(a3, self._split_weight(module).t(), out_dtype=torch.float32)
         half = self.split_dtype
-        xs = rag_hip.enc_split_bf16x3_dev(x, half)
+        if xs is None:
+            xs = rag_hip.enc_split_bf16x3_dev(x, half)
         last = len(self.layers) - 1
         head_dim = self.config.hidden_size // self.config.num_attention_heads
         mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)

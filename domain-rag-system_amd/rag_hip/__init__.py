@@ -72,6 +72,8 @@ SIGNATURES = {
     'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
+    'rag_enc_embed_layernorm_split_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
+                                                 _i32, _vp, _i32, _vp, _vp]),
     'rag_enc_mlp_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
     'rag_filter_mask_dev': (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
     'rag_dense_reserve': (_i32, [_vp, _i32, _i32]),
@@ -789,6 +791,28 @@ def enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, be
                                             type_emb.shape[0], DTYPE_BF16 if dt == torch.bfloat16 else DTYPE_F32,
                                             _ptr(out), _stream()), 'rag_enc_embed_layernorm_dev')
     return out
+
+
+def enc_embed_layernorm_split_dev(ids, types, pos, word, position, type_emb, gamma, beta, eps, half=None):
+    """enc_embed_layernorm_dev for float32 tables that also returns the rows split for the first split-precision GEMM
+    (rag_enc_embed_layernorm_split_dev): (out fp32 [T, H], [T, 3H] = [hi | hi | lo] in `half`)."""
+    import torch
+    t = ids.shape[0]
+    hidden = word.shape[1]
+    if word.dtype != torch.float32:
+        raise ValueError("enc_embed_layernorm_split_dev handles float32 tables")
+    if tuple(pos.shape) != (t,) or (types is not None and tuple(types.shape) != (t,)):
+        raise ValueError("ids, types and pos must have one entry per token")
+    code, hdt = _half_code(half)
+    out = torch.empty((t, hidden), dtype=torch.float32, device=ids.device)
+    split = torch.empty((t, 3 * hidden), dtype=hdt, device=ids.device)
+    f32 = torch.float32
+    check(lib().rag_enc_embed_layernorm_split_dev(_ptr(ids, torch.int32), _ptr(types, torch.int32), _ptr(pos, torch.int32),
+                                                  _ptr(word, f32), _ptr(position, f32), _ptr(type_emb, f32), _ptr(gamma, f32),
+                                                  _ptr(beta, f32), float(eps), t, hidden, word.shape[0], position.shape[0],
+                                                  type_emb.shape[0], _ptr(out), code, _ptr(split), _stream()),
+          'rag_enc_embed_layernorm_split_dev')
+    return out, split
 
 
 def ce_pack_packed_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair_query, pair_row, cu,

@@ -476,6 +476,16 @@ int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, co
                                 const void* d_gamma, const void* d_beta, float eps, int64_t n_tokens,
                                 int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
                                 int32_t dtype, void* d_out, void* stream);
+/* The same for fp32 tables with the row also written as [hi | hi | lo] in `half_dtype` (out_split
+ * [n_tokens][3 * hidden], what rag_enc_split_bf16x3_dev makes of `out`): the embedding output of
+ * transformers' BertEmbeddings as the left operand of the first split-precision GEMM, in one pass
+ * (reached through CrossEncoder.predict / SentenceTransformer.encode, reference
+ * src/reranker/rerank.py:79-84, src/indexing/embedder.py:65-71).                                  */
+int rag_enc_embed_layernorm_split_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
+                                      const float* d_word, const float* d_position, const float* d_type_emb,
+                                      const float* d_gamma, const float* d_beta, float eps, int64_t n_tokens,
+                                      int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
+                                      float* d_out, int32_t half_dtype, void* d_out_split, void* stream);
 /* out[r] = LayerNorm(x[r] + residual[r]) * gamma + beta over `hidden` elements per row
  * (residual may be NULL); fp32 arithmetic, inputs/outputs bf16 or fp32 as `dtype` says;
  * hidden a multiple of 8 up to 2048.  out may alias x or residual.                     */

@@ -432,3 +432,30 @@ def test_cross_encoder_reranker_packed_path_matches_padded_fp32():
     a, b = fast.score_pairs(pairs), plain.score_pairs(pairs)
     assert len(a) == len(pairs)
     assert max(abs(x - y) for x, y in zip(a, b)) < 1e-4
+
+
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16])
+def test_embed_layernorm_split_equals_the_two_passes(half):
+    """rag_enc_embed_layernorm_split_dev: the fp32 rows and their [hi | hi | lo] split, bit for bit what
+    rag_enc_embed_layernorm_dev followed by rag_enc_split_bf16x3_dev give (ragged token count, clamped ids flagged)."""
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(3)
+    h, vocab, max_pos, n_types, t = 384, 1000, 128, 2, 1001
+    word = torch.randn((vocab, h), generator=g, device=dev)
+    position = torch.randn((max_pos, h), generator=g, device=dev) * 0.1
+    type_emb = torch.randn((n_types, h), generator=g, device=dev) * 0.1
+    gamma = torch.rand((h,), generator=g, device=dev) + 0.5
+    beta = torch.randn((h,), generator=g, device=dev) * 0.1
+    ids = torch.randint(0, vocab, (t,), generator=g, device=dev, dtype=torch.int32)
+    types = torch.randint(0, n_types, (t,), generator=g, device=dev, dtype=torch.int32)
+    pos = torch.randint(0, max_pos, (t,), generator=g, device=dev, dtype=torch.int32)
+    want = rag_hip.enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, beta, 1e-12)
+    want_split = rag_hip.enc_split_bf16x3_dev(want, half)
+    got, got_split = rag_hip.enc_embed_layernorm_split_dev(ids, types, pos, word, position, type_emb, gamma, beta, 1e-12, half)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert got_split.dtype == half and torch.equal(got_split.view(torch.int16), want_split.view(torch.int16))
+    rag_hip.check_faults()
+    with pytest.raises(ValueError):
+        rag_hip.enc_embed_layernorm_split_dev(ids, types, pos, word.bfloat16(), position, type_emb, gamma, beta, 1e-12, half)
