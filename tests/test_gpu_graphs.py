@@ -114,3 +114,29 @@ def test_class_api_single_calls_replay_graphs(monkeypatch):
         assert a.shape == b.shape == (1, 768) and float(np.abs(a - b).max()) < 1e-6
     for a, b in zip(got_l, want_l):
         assert len(a) == len(b) and float(np.abs(np.asarray(a) - np.asarray(b)).max()) < 2e-6
+
+
+def test_bm25_on_a_second_stream_changes_nothing(monkeypatch):
+    """Batches of four queries and more run the BM25 search on a second stream beside the embedder and the dense scan
+    (RAG_OVERLAP_BM25=0 keeps one stream): identical results, several batches in a row."""
+    from indexing.batch import BatchSearcher, TokenStore
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    w = _world(dev)
+    mk = lambda: BatchSearcher(w['dense'], w['bm25'], bi_encoder=w['bi'], cross_encoder=w['ce'],
+                               chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=20)
+    two = mk()
+    monkeypatch.setenv('RAG_OVERLAP_BM25', '0')
+    one = mk()
+    monkeypatch.delenv('RAG_OVERLAP_BM25')
+    assert two.overlap_bm25 and not one.overlap_bm25
+    for seed in (1, 2, 3):
+        q = _queries(w, 37, 900 + seed, dev)
+        a, e = two.search(*q), one.search(*q)
+        torch.cuda.synchronize()
+        for key in ('fused_row', 'fused_score', 'fused_count', 'rows', 'count', 'logits'):
+            assert torch.equal(a[key], e[key]), key
+    assert two._bm25_stream is not None and one._bm25_stream is None
+    w['dense'].close()
+    w['bm25'].close()
