@@ -573,7 +573,7 @@ def main():
             qs = make_queries(sub, nx + 1, dev, seed=300 + bsz)
             # (small batches replay their encoder forwards from HIP graphs, captured per shape bucket the first time
             # a shape is seen: every batch of the list runs once before the list is timed, a warmed server's latency)
-            v, ms = time_steps(searcher, qs[1:], n_warm=len(qs) - 1 if bsz <= 16 else 1)
+            v, ms = time_steps(searcher, qs[1:], n_warm=len(qs) - 1 if bsz <= 32 else 1)
             sweep.append({'batch': bsz, 'latency_ms': ms, 'value': v})
         extra['batch_sweep'] = sweep
         # the same step when the boundary hands over HOST buffers: queries copied in from pinned memory and the

@@ -117,10 +117,10 @@ class BatchSearcher:
         self.overlap_bm25 = os.environ.get('RAG_OVERLAP_BM25', '1') != '0'
         self._bm25_stream = None
         # HIP graphs for the two encoder forwards of very small batches (RAG_GRAPHS=0 switches them off)
-        # (measured, 1M rows, 50 pairs per query: the embedder's graph wins up to 16 queries, 2.1 -> 0.9-1.3 ms; the
+        # (measured, 1M rows, 50 pairs per query: the embedder's graph wins up to 32 queries, 2.1 -> 0.9-1.8 ms; the
         # cross-encoder's up to 4, beyond that its forward is no longer launch bound)
         off = os.environ.get('RAG_GRAPHS') == '0'
-        self.graph_max_batch = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '16'))
+        self.graph_max_batch = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '32'))
         self.graph_max_batch_ce = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH_CE', '4'))
         self._graphs = {}
 
@@ -207,17 +207,20 @@ class BatchSearcher:
         bert = self.bi_encoder.bert
         if (getattr(bert, 'native', False) and self._graph_ok(ids.shape[0], ids.device)
                 and bert.word.weight.dtype == torch.float32 and getattr(bert, 'split_gemm', False)):
-            s = (ids.shape[1] + 31) // 32 * 32           # one graph per 32 columns of padded width
-            if s != ids.shape[1]:
-                ids = torch.nn.functional.pad(ids, (0, s - ids.shape[1]))
-                mask = torch.nn.functional.pad(mask, (0, s - mask.shape[1]))
+            s = (ids.shape[1] + 31) // 32 * 32           # one graph per 32 columns of padded width ...
+            b = ids.shape[0]
+            b_pad = 1 << (b - 1).bit_length()            # ... and per power of two of queries (empty rows beyond the batch)
+            if s != ids.shape[1] or b_pad != b:
+                ids = torch.nn.functional.pad(ids, (0, s - ids.shape[1], 0, b_pad - b))
+                mask = torch.nn.functional.pad(mask, (0, s - mask.shape[1], 0, b_pad - b))
 
             def fwd(i, m):
                 p_ids, p_types, p_pos, cu = pack_static(i, m)
                 return self.bi_encoder.forward_packed(p_ids, p_types, p_pos, cu, s, normalize=True)
             g = self._graphed(('embed', ids.shape[0], s, ids.dtype, mask.dtype), fwd, [ids, mask])
             if g is not None:
-                return g(ids, mask).clone()
+                return g(ids, mask)[:b].clone()
+            ids, mask = ids[:b], mask[:b]
         if getattr(self.bi_encoder.bert, 'native', False):
             # unpadded: queries differ a lot in length, and padding positions cost full GEMM rows
             p_ids, p_types, p_pos, cu, longest = self.bi_encoder.bert.pack(ids, mask)
