@@ -452,6 +452,8 @@ def main():
                            'ms_per_step': round(f_s * 1e3 / max(args.steps, 1), 2),
                            'algorithmic_gbs': round(f_bytes / f_s / 1e9, 1),
                            'hbm_frac': round(f_bytes / f_s / 1e9 / HBM_PEAK_GBS, 4)}
+            if len(lls_ms) >= 1024:      # the hooks' event ring was full: the figures cover the run's first launches only
+                roofline_ff['profile_ring_full'] = True
             if (~sel).any():      # the same kernel as attention-output projection (K = hidden, operand already split)
                 o_rows, o_s = float(lls_rows[~sel].sum()), float(lls_ms[~sel].sum()) / 1e3
                 roofline_ff['attention_output_form'] = {
