@@ -117,3 +117,33 @@ def test_bm25_save_load_roundtrip(tmp_path):
     assert ix2.get_stats() == ix.get_stats()
     with pytest.raises(ValueError):
         BM25Indexer().search("x")
+
+
+def test_bm25_long_queries_and_dense_terms():
+    """Queries of more than 32 tokens (the kernel looks posting ranges up 32 tokens at a time) and terms that
+    nearly every document of a tile contains (more postings per tile than the kernel fetches ahead): scores and
+    lists bit-identical to the oracle, repeated and out-of-vocabulary tokens included."""
+    import rag_hip
+    from indexing.bm25_indexer import build_arrays
+    n_docs, vocab = 9000, 40                                  # 40 terms over 9000 documents: dense posting lists
+    term, doc, ln = synth.sparse_corpus(n_docs, vocab, seed=77, mean_len=30)
+    term, mapping, v = synth.remap_first_appearance(term, vocab)
+    ref = BM25OkapiArrays.from_token_ids(term, doc, ln, v)
+    arr = build_arrays(term, doc, ln, v, 1.5, 0.75)
+    idx = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, n_docs)
+    rng = np.random.default_rng(78)
+    queries = []
+    for n_tok in (31, 32, 33, 64, 65, 100, 3):
+        q = rng.integers(0, v, size=n_tok).tolist()
+        q[n_tok // 2] = -1                                     # one out-of-vocabulary token in the middle
+        queries.append(q)
+    queries.append([0] * 40)                                   # the most frequent term forty times
+    score, row, cnt = idx.search(queries, 50)
+    for i, q in enumerate(queries):
+        want = ref.get_scores_ids(q)
+        assert np.array_equal(idx.scores(q), want), i
+        order = rank_rows_ref(want, 50)
+        assert int(cnt[i]) == 50
+        assert np.array_equal(row[i], order), i
+        assert np.array_equal(score[i], want[order])
+    idx.close()
