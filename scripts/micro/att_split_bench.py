@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--tokens', type=int, default=1_000_000)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--mean', type=float, default=45.0)
+    ap.add_argument('--clip', type=int, default=0, help='cut every sequence to this many tokens')
+    ap.add_argument('--lds-for', type=int, default=0, help='size the LDS image for this sequence length (>= the longest)')
     args = ap.parse_args()
     import rag_hip
     rag_hip.init(0)
@@ -29,12 +31,14 @@ def main():
         chunk = int(np.clip(np.rint(rng.lognormal(np.log(args.mean), 0.6)), 2, 128)) + 2
         lens.append(chunk + int(rng.integers(8, 25)) + 3)
     lens = np.sort(np.asarray(lens))[::-1].copy()
+    if args.clip:
+        lens = np.minimum(lens, args.clip)
     t = int(lens.sum())
     cu = torch.zeros(len(lens) + 1, dtype=torch.int32, device=dev)
     cu[1:] = torch.cumsum(torch.from_numpy(lens).to(dev), 0)
     qkv = torch.randn((t, 3 * 384), device=dev)
     bias = torch.randn((3 * 384,), device=dev) * 0.1
-    longest = int(lens.max())
+    longest = max(int(lens.max()), args.lds_for)
     for first in (False,):
         fn = lambda: rag_hip.enc_attention_split_dev(qkv, bias, cu, longest, 12, first_only=first, half=torch.float16)
         fn(); fn()
