@@ -292,6 +292,13 @@ class BertEncoder(nn.Module):
         fused_out = (self.fused_split_out and x.shape[0] >= int(os.environ.get('RAG_FUSED_OUT_MIN_TOKENS', '12288'))
                      and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, half)
                      and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, half))
+        # (the library's GEMM tiles are 256 columns wide: [T, 1152] pads its last tile by half, [T, 768] + [T, 384] ran
+        # 3-4 ms of 277 faster on 750 k tokens; 512 | 640 and three products of 384 were no faster, five of 256 slower)
+        qkv_cuts = os.environ.get('RAG_QKV_SPLIT_N')
+        if qkv_cuts is None:
+            qkv_cuts = [2 * c.hidden_size] if (fused_out and c.hidden_size % 128 == 0 and c.hidden_size % 256) else []
+        else:
+            qkv_cuts = [int(v) for v in qkv_cuts.split(',') if int(v) > 0]
         for li, l in enumerate(self.layers):
             cls_only = first_token_only and li == last
             if mfma_attn:
@@ -305,6 +312,12 @@ class BertEncoder(nn.Module):
                     torch.mm(xs, w3[hdim:].t(), out_dtype=torch.float32, out=qkv[:, hdim:])
                     first = cu_seqlens[:-1].long()
                     qkv[first, :hdim] = torch.mm(xs[first], w3[:hdim].t(), out_dtype=torch.float32)
+                elif qkv_cuts:
+                    # q|k apart from v: each product's width is then a whole number of the library's 256-wide tiles
+                    w3 = self._split_weight(l.qkv)
+                    qkv = torch.empty((xs.shape[0], w3.shape[0]), dtype=torch.float32, device=xs.device)
+                    for a, z in zip([0] + qkv_cuts, qkv_cuts + [w3.shape[0]]):
+                        torch.mm(xs, w3[a:z].t(), out_dtype=torch.float32, out=qkv[:, a:z])
                 else:
                     qkv = mm(xs, l.qkv)
                 ctx3 = rag_hip.enc_attention_split_dev(qkv, l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
