@@ -329,7 +329,7 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
                                                                     const float* __restrict__ bias,
                                                                     const int32_t* __restrict__ cu, int64_t total_tokens,
                                                                     int n_seq, int S_max, int NH, float scale,
-                                                                    int first_only, H16* __restrict__ out,
+                                                                    int first_only, int out_hl, H16* __restrict__ out,
                                                                     uint32_t* fault) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Half16<H16>::x8 hx8;
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
     const int len = (int)n;
     const float* base = qkv + (size_t)first * tok + head * D;
     const float* bq = bias != nullptr ? bias + head * D : nullptr;
-    H16* obase = (first_only ? out + (size_t)seq * tok : out + (size_t)first * tok) + head * D;
+    const size_t otok = out_hl ? (size_t)2 * H : tok;     // output row: [hi | lo] or [hi | hi | lo]
+    H16* obase = (first_only ? out + (size_t)seq * otok : out + (size_t)first * otok) + head * D;
     const int kpad = (len + 31) & ~31;
     const int VROW = kpad + 4;
     H16* Kh = reinterpret_cast<H16*>(smem);
@@ -522,10 +523,14 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
                     for (int j = 0; j < 8; ++j) {
                         RAG_SPLIT_HI_LO(H16, run[u][j], hi[j], lo[j]);
                     }
-                    H16* dst = obase + (size_t)q * tok + dt * 32 + 8 * h + 16 * u;
+                    H16* dst = obase + (size_t)q * otok + dt * 32 + 8 * h + 16 * u;
                     *reinterpret_cast<hx8*>(dst) = hi;
-                    *reinterpret_cast<hx8*>(dst + H) = hi;
-                    *reinterpret_cast<hx8*>(dst + 2 * H) = lo;
+                    if (out_hl) {
+                        *reinterpret_cast<hx8*>(dst + H) = lo;
+                    } else {
+                        *reinterpret_cast<hx8*>(dst + H) = hi;
+                        *reinterpret_cast<hx8*>(dst + 2 * H) = lo;
+                    }
                 }
             }
         }
@@ -958,10 +963,10 @@ extern "C" int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32
                             d_out, stream_, 1);
 }
 
-extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
-                                           int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
-                                           int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out,
-                                           void* stream_) {
+namespace {
+int attention_split_launch(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens, int32_t n_seq,
+                           int64_t total_tokens, int32_t max_seq_len, int32_t n_heads, int32_t head_dim,
+                           int32_t first_only, int32_t half_dtype, int32_t out_hl, void* d_out, void* stream_) {
     RAG_REQUIRE(half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16, RAG_EINVAL,
                 "rag_enc_attention_split: the halves are bf16 or fp16");
     RAG_REQUIRE(n_seq >= 0 && max_seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention_split: bad sizes");
@@ -985,8 +990,8 @@ extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bi
     do {                                                                                                               \
         if (lds > 64 * 1024) RAG_GRANT_LDS((attention_split_kernel<DD, HH>), 160 * 1024);                              \
         attention_split_kernel<DD, HH><<<grid, nt, lds, stream>>>(d_qkv, d_bias, d_cu_seqlens, total_tokens, n_seq,    \
-                                                                  max_seq_len, n_heads, scale, first_only, (HH*)d_out, \
-                                                                  rag_fault_word());                                  \
+                                                                  max_seq_len, n_heads, scale, first_only, out_hl,     \
+                                                                  (HH*)d_out, rag_fault_word());                       \
     } while (0)
     if (head_dim == 32 && half_dtype == RAG_DTYPE_BF16) RAG_ATT_SPLIT_LAUNCH(32, bf16);
     else if (head_dim == 32) RAG_ATT_SPLIT_LAUNCH(32, f16);
@@ -995,6 +1000,23 @@ extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bi
 #undef RAG_ATT_SPLIT_LAUNCH
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
+                                           int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                           int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out,
+                                           void* stream_) {
+    return attention_split_launch(d_qkv, d_bias, d_cu_seqlens, n_seq, total_tokens, max_seq_len, n_heads, head_dim,
+                                  first_only, half_dtype, 0, d_out, stream_);
+}
+
+extern "C" int rag_enc_attention_split_hl_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
+                                              int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                              int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out,
+                                              void* stream_) {
+    return attention_split_launch(d_qkv, d_bias, d_cu_seqlens, n_seq, total_tokens, max_seq_len, n_heads, head_dim,
+                                  first_only, half_dtype, 1, d_out, stream_);
 }
 
 namespace {

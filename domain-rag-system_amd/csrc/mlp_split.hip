@@ -63,7 +63,8 @@ __device__ unsigned long long fs_dbg[8];
 
 struct FfnOutParams {
     const float* h;        // SRC 0: [M][K] fp32, the first product without its bias
-    const f16* hs;         // SRC 1: [M][3K] fp16, a finished operand already split as [hi | hi | lo]
+    const f16* hs;         // SRC 1: fp16, a finished operand already split: [M][3K] = [hi | hi | lo], or [M][2K] = [hi | lo]
+    int hs_hl;             // SRC 1: rows are [hi | lo]
     const float* b1;       // SRC 0: [K] bias added before the activation
     const f16* wh;         // high halves of W [384][K], packed by chunk (pack_weights_kernel)
     const f16* wl;         // low halves, packed the same way
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
     //          loads 0, 1 bring rows 0-15, 16-31 of the high image, loads 2, 3 those of the low image.
     constexpr int CHUNK_BYTES = SRC == 0 ? FS_C * 4 : FS_C * 2;
     constexpr int N_OPOFF = SRC == 0 ? 4 : 2;
-    const size_t row_bytes = SRC == 0 ? (size_t)p.K * 4 : (size_t)p.K * 6;
+    const size_t row_bytes = SRC == 0 || p.hs_hl ? (size_t)p.K * 4 : (size_t)p.K * 6;
+    const size_t lo_bytes = p.hs_hl ? 2 * (size_t)p.K : 4 * (size_t)p.K;         // SRC 1: where a row's low halves start
     const unsigned char* op_base = (SRC == 0 ? reinterpret_cast<const unsigned char*>(p.h) : reinterpret_cast<const unsigned char*>(p.hs))
                                    + (size_t)tok_wg * row_bytes;
     uint32_t opoff[N_OPOFF];
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
         constexpr int I = decltype(i_c)::value;
         const uint32_t dst = op_lds + slot * FS_OP_SLOT + 1024 * I;
         if constexpr (SRC == 0) lds_dma16(dst, op_base + (size_t)c * CHUNK_BYTES, opoff[I]);
-        else lds_dma16(dst, op_base + (I >= 2 ? 4 * (size_t)p.K : 0) + (size_t)c * CHUNK_BYTES, opoff[I & 1]);
+        else lds_dma16(dst, op_base + (I >= 2 ? lo_bytes : 0) + (size_t)c * CHUNK_BYTES, opoff[I & 1]);
     };
     auto dma_op_all = [&](int c, int slot) {
         unrolled(std::make_integer_sequence<int, 4>{}, [&](auto i_c) { dma_op(c, slot, i_c); });
@@ -569,6 +571,8 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
     RAG_REQUIRE(k >= FS_C && k % FS_C == 0 && k <= FS_MAX_K, RAG_ELIMIT,
                 "rag_enc_linear_ln_split: the input width must be a multiple of %d up to %d (got %d)", FS_C, FS_MAX_K, k);
     RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_linear_ln_split: negative row count");
+    RAG_REQUIRE(in_is_split >= 0 && in_is_split <= 2, RAG_EINVAL, "rag_enc_linear_ln_split: in_is_split is 0, 1 or 2 (got %d)",
+                in_is_split);
     if (m == 0) return RAG_OK;
     RAG_REQUIRE(d_in && d_wh && d_wl && d_b2 && d_residual && d_gamma && d_beta && d_y && (in_is_split || d_b1), RAG_EINVAL,
                 "rag_enc_linear_ln_split: null pointer");
@@ -578,6 +582,7 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
     RAG_REQUIRE(ceil_div64(m, FS_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear_ln_split: too many rows");
     FfnOutParams p = {};
     if (in_is_split) p.hs = (const f16*)d_in; else p.h = (const float*)d_in;
+    p.hs_hl = in_is_split == 2;
     p.b1 = d_b1; p.wh = (const f16*)d_wh; p.wl = (const f16*)d_wl; p.b2 = d_b2; p.residual = d_residual;
     p.gamma = d_gamma; p.beta = d_beta; p.y = d_y; p.ys = (f16*)d_y_split; p.M = m; p.K = k; p.eps = eps;
     const size_t lds = (size_t)FS_OFF_B1 + 4 * ((size_t)k + 3 * FS_HID);

@@ -320,8 +320,11 @@ class BertEncoder(nn.Module):
                         torch.mm(xs, w3[a:z].t(), out_dtype=torch.float32, out=qkv[:, a:z])
                 else:
                     qkv = mm(xs, l.qkv)
+                # (the fused output kernel reads the halves where they lie: [hi | lo] rows, a third less for attention to
+                # write; a library GEMM needs [hi | hi | lo])
                 ctx3 = rag_hip.enc_attention_split_dev(qkv, l.qkv.bias, cu_seqlens, max_seq_len, l.heads,
-                                                       first_only=cls_only, half=half)
+                                                       first_only=cls_only, half=half,
+                                                       hi_lo=fused_out and os.environ.get('RAG_ATT_HI_LO', '1') != '0')
             else:
                 qkv = mm(xs, l.qkv).add_(l.qkv.bias)
                 ctx = rag_hip.enc_attention_packed_dev(qkv, cu_seqlens, max_seq_len, l.heads)

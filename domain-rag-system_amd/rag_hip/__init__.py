@@ -70,6 +70,7 @@ SIGNATURES = {
     'rag_enc_attention_packed_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_packed_first_dev': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_attention_split_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_attention_split_hl_dev': (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
                                            _i32, _i32, _vp, _vp]),
     'rag_enc_embed_layernorm_split_dev': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _i32,
@@ -939,20 +940,21 @@ def _half_code(half):
     raise ValueError(f"split-precision halves are bfloat16 or float16, not {half}")
 
 
-def enc_attention_split_dev(qkv, bias, cu_seqlens, max_seq_len, n_heads, first_only=False, half=None):
+def enc_attention_split_dev(qkv, bias, cu_seqlens, max_seq_len, n_heads, first_only=False, half=None, hi_lo=False):
     """fp32-equivalent attention of a packed batch (rag_enc_attention_split_dev): qkv [T, 3*H] fp32 without
-    its bias, bias [3*H] fp32 or None -> `half` [T or n_seq, 3*H] = [hi | hi | lo] of the attention output."""
+    its bias, bias [3*H] fp32 or None -> `half` [T or n_seq, 3*H] = [hi | hi | lo] of the attention output, or with
+    hi_lo (rag_enc_attention_split_hl_dev) [T or n_seq, 2*H] = [hi | lo]."""
     import torch
     code, hdt = _half_code(half)
     t, h3 = qkv.shape
     n_seq = cu_seqlens.shape[0] - 1
     if bias is not None and tuple(bias.shape) != (h3,):
         raise ValueError("bias must have one entry per projection column")
-    out = torch.empty((n_seq if first_only else t, h3), dtype=hdt, device=qkv.device)
-    check(lib().rag_enc_attention_split_dev(_ptr(qkv, torch.float32), _ptr(bias, torch.float32),
-                                            _ptr(cu_seqlens, torch.int32), n_seq, t, int(max_seq_len), int(n_heads),
-                                            (h3 // 3) // int(n_heads), 1 if first_only else 0, code, _ptr(out), _stream()),
-          'rag_enc_attention_split_dev')
+    out = torch.empty((n_seq if first_only else t, 2 * (h3 // 3) if hi_lo else h3), dtype=hdt, device=qkv.device)
+    fn = lib().rag_enc_attention_split_hl_dev if hi_lo else lib().rag_enc_attention_split_dev
+    check(fn(_ptr(qkv, torch.float32), _ptr(bias, torch.float32), _ptr(cu_seqlens, torch.int32), n_seq, t, int(max_seq_len),
+             int(n_heads), (h3 // 3) // int(n_heads), 1 if first_only else 0, code, _ptr(out), _stream()),
+          'rag_enc_attention_split_hl_dev' if hi_lo else 'rag_enc_attention_split_dev')
     return out
 
 
@@ -1106,15 +1108,17 @@ def enc_linear_ln_split_supported(k, n, half):
 
 def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, want_split=True):
     """LayerNorm(residual + a @ W.T + b2) * gamma + beta at fp32 precision on the fp16 matrix cores
-    (rag_enc_linear_ln_split_dev).  x_in fp32 [M, K] with b1: a = GELU(x_in + b1); x_in fp16 [M, 3K] (b1 None): a is
-    that split operand.  wh, wl: split_weight_halves(W), W [384, K].  Returns (y fp32 [M, 384], its fp16
-    [hi | hi | lo] split [M, 1152] or None)."""
+    (rag_enc_linear_ln_split_dev).  x_in fp32 [M, K] with b1: a = GELU(x_in + b1); x_in fp16 [M, 3K] = [hi | hi | lo]
+    or [M, 2K] = [hi | lo] (b1 None): a is that split operand.  wh, wl: split_weight_halves(W), W [384, K].  Returns
+    (y fp32 [M, 384], its fp16 [hi | hi | lo] split [M, 1152] or None)."""
     import torch
     m = x_in.shape[0]
     n, k = wh.shape
     is_split = x_in.dtype == torch.float16
-    if tuple(x_in.shape) != (m, 3 * k if is_split else k) or (not is_split and x_in.dtype != torch.float32):
-        raise ValueError("x_in must be fp32 [M, K] or fp16 [M, 3K]")
+    if is_split and tuple(x_in.shape) == (m, 2 * k):
+        is_split = 2
+    elif tuple(x_in.shape) != (m, 3 * k if is_split else k) or (not is_split and x_in.dtype != torch.float32):
+        raise ValueError("x_in must be fp32 [M, K] or fp16 [M, 3K] or [M, 2K]")
     if not is_split and (b1 is None or tuple(b1.shape) != (k,)):
         raise ValueError("an fp32 input needs its bias b1 [K]")
     if tuple(wl.shape) != (n, k) or tuple(residual.shape) != (m, n):
@@ -1125,7 +1129,7 @@ def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, wa
     y = torch.empty((m, n), dtype=torch.float32, device=x_in.device)
     ys = torch.empty((m, 3 * n), dtype=torch.float16, device=x_in.device) if want_split else None
     f32 = torch.float32
-    check(lib().rag_enc_linear_ln_split_dev(_ptr(x_in), 1 if is_split else 0, None if is_split else _ptr(b1, f32),
+    check(lib().rag_enc_linear_ln_split_dev(_ptr(x_in), int(is_split), None if is_split else _ptr(b1, f32),
                                             _ptr(wh, torch.float16), _ptr(wl, torch.float16), _ptr(b2, f32),
                                             _ptr(residual, f32), _ptr(gamma, f32), _ptr(beta, f32), float(eps), m, k, n,
                                             _ptr(y), _ptr(ys) if ys is not None else None, _stream()),

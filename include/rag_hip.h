@@ -359,6 +359,12 @@ int rag_enc_attention_packed_first_dev(const void* d_qkv, const int32_t* d_cu_se
 int rag_enc_attention_split_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
                                 int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
                                 int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out, void* stream);
+/* The same with out [rows][2 * H]: row = [hi | lo], a third less to write.  For a consumer that reads the two
+ * halves where they lie (rag_enc_linear_ln_split_dev with in_is_split == 2) rather than a library GEMM over
+ * [hi | hi | lo].                                                                                  */
+int rag_enc_attention_split_hl_dev(const float* d_qkv, const float* d_bias, const int32_t* d_cu_seqlens,
+                                   int32_t n_seq, int64_t total_tokens, int32_t max_seq_len, int32_t n_heads,
+                                   int32_t head_dim, int32_t first_only, int32_t half_dtype, void* d_out, void* stream);
 /* Sentence embedding of a packed fp32 batch: out[i] = mean of x over the tokens of
  * sequence i (the mean pooling over the attention mask of the sentence-transformers
  * pipeline behind reference src/indexing/embedder.py:65-71), L2-normalised when
@@ -447,8 +453,9 @@ int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, 
  *   y[m] = LayerNorm(residual[m] + a[m] W^T + b2) * gamma + beta,      W [n = 384][k], y fp32 [m][384]
  * where the left operand a is, with in_is_split == 0,  a = GELU(in + b1)  for in fp32 [m][k], the first
  * product of the feed-forward block without its bias (erf GELU, evaluated to fp32 round-off), or, with
- * in_is_split != 0, the operand given by in = fp16 [m][3k] rows [hi | hi | lo] (what rag_enc_split_bf16x3_dev
- * and rag_enc_attention_split_dev write with RAG_DTYPE_F16; b1 is ignored).  W comes as its fp16 halves
+ * in_is_split == 1, the operand given by in = fp16 [m][3k] rows [hi | hi | lo] (what rag_enc_split_bf16x3_dev
+ * and rag_enc_attention_split_dev write with RAG_DTYPE_F16; b1 is ignored), or, with in_is_split == 2, by
+ * in = fp16 [m][2k] rows [hi | lo] (rag_enc_attention_split_hl_dev).  W comes as its fp16 halves
  * wh = fp16(W), wl = fp16(W - wh), each 384 * k elements packed by rag_enc_linear_ln_split_pack_dev (once per
  * weight: the kernel streams them chunk by chunk).  The product is hi.hi + lo.hi + hi.lo with fp32
  * accumulation; bias, residual and LayerNorm are fp32.  d_y_split (may be NULL): fp16 [m][1152] rows

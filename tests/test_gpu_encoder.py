@@ -324,6 +324,13 @@ def test_split_attention_matches_fp64_and_first_only(heads, head_dim, max_len, n
     assert torch.equal(out3[:, :hid], out3[:, hid:2 * hid])
     assert torch.equal(first3, out3[cu[:-1].long()])
     assert torch.equal(nobias3, out3)
+    # rag_enc_attention_split_hl_dev: the same halves as [hi | lo] rows
+    out2 = rag_hip.enc_attention_split_dev(qkv, bias, cu, max_len, heads, half=hdt, hi_lo=True)
+    first2 = rag_hip.enc_attention_split_dev(qkv, bias, cu, max_len, heads, first_only=True, half=hdt, hi_lo=True)
+    torch.cuda.synchronize()
+    assert tuple(out2.shape) == (t, 2 * hid) and tuple(first2.shape) == (n_seq, 2 * hid)
+    assert torch.equal(out2[:, :hid], out3[:, :hid]) and torch.equal(out2[:, hid:], out3[:, 2 * hid:])
+    assert torch.equal(first2, out2[cu[:-1].long()])
     got = out3[:, :hid].double() + out3[:, 2 * hid:].double()
     full = (qkv + bias).double()
     cu_h = cu.cpu().tolist()

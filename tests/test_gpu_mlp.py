@@ -212,6 +212,10 @@ def test_linear_ln_split_matches_float64(m, k):
     y3, _ = rag_hip.enc_linear_ln_split_dev(a3, None, wh, wl, b2, res, gamma, beta, 1e-12)
     err3 = float((y3.double() - ref(h.double())).abs().max())
     assert err3 < max(3 * err_plain, 2e-6), (err3, err_plain)
+    # the same operand as [hi | lo] rows (in_is_split == 2): the same result bit for bit
+    a2 = torch.cat([a3[:, :k], a3[:, 2 * k:]], dim=1).contiguous()
+    y4, s4 = rag_hip.enc_linear_ln_split_dev(a2, None, wh, wl, b2, res, gamma, beta, 1e-12)
+    assert torch.equal(y4, y3) and torch.equal(s4, _)
     # the separate route it replaces: library GEMM on [hi|hi|lo] operands + bias/residual/LayerNorm kernel
     w3 = rag_hip.split_weight_bf16x3(w, torch.float16)
     sep, _ = rag_hip.enc_bias_add_layernorm_split_dev(torch.mm(a3, w3.t(), out_dtype=torch.float32), b2, res, gamma, beta,
