@@ -69,10 +69,11 @@ struct FfnOutParams {
     const f16* wh;         // high halves of W [384][K], packed by chunk (pack_weights_kernel)
     const f16* wl;         // low halves, packed the same way
     const float* b2;       // [384]
-    const float* residual; // [M][384]
+    const float* residual; // [M][384], or null with
+    const f16* residual_s; // [M][1152] fp16 rows [hi | hi | lo]: the residual is hi + lo (the ys of the call that made it)
     const float* gamma;    // [384]
     const float* beta;     // [384]
-    float* y;              // [M][384]
+    float* y;              // [M][384], or null (only ys is wanted)
     f16* ys;               // [M][1152] = [hi | hi | lo] of y, or null
     int64_t M;
     int K;
@@ -403,14 +404,29 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
     const float* gs = b2s + FS_HID;
     const float* bs = gs + FS_HID;
     f32x4 rs[12];                                             // residual of the pass ahead
-    {
-        const float* res = p.residual + min(tok0, p.M - 1) * FS_HID + 8 * l8;
+    auto load_residual = [&](int64_t tok) {
+        if (p.residual_s != nullptr) {                        // fp16 halves of the row: hi + lo is exact in fp32
+            const f16* res = p.residual_s + min(tok, p.M - 1) * (3 * FS_HID) + 8 * l8;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            rs[2 * j] = *reinterpret_cast<const f32x4*>(res + 64 * j);
-            rs[2 * j + 1] = *reinterpret_cast<const f32x4*>(res + 64 * j + 4);
+            for (int j = 0; j < 6; ++j) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(res + 64 * j);
+                const f16x8 b = *reinterpret_cast<const f16x8*>(res + 2 * FS_HID + 64 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rs[2 * j][i] = (float)a[i] + (float)b[i];
+                    rs[2 * j + 1][i] = (float)a[4 + i] + (float)b[4 + i];
+                }
+            }
+        } else {
+            const float* res = p.residual + min(tok, p.M - 1) * FS_HID + 8 * l8;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                rs[2 * j] = *reinterpret_cast<const f32x4*>(res + 64 * j);
+                rs[2 * j + 1] = *reinterpret_cast<const f32x4*>(res + 64 * j + 4);
+            }
         }
-    }
+    };
+    load_residual(tok0);
 #pragma nounroll
     for (int half = 0; half < 2; ++half) {
         if ((r >> 4) == half) {
@@ -450,14 +466,7 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
                     sum += v[8 * j + 4 + i];
                 }
             }
-            if (q < 3) {                                      // the next pass's residual, in flight during this pass
-                const float* res = p.residual + min(tok_q + 8, p.M - 1) * FS_HID + 8 * l8;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    rs[2 * j] = *reinterpret_cast<const f32x4*>(res + 64 * j);
-                    rs[2 * j + 1] = *reinterpret_cast<const f32x4*>(res + 64 * j + 4);
-                }
-            }
+            if (q < 3) load_residual(tok_q + 8);             // the next pass's residual, in flight during this pass
             sum += __shfl_xor(sum, 1, 64);
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 4, 64);
@@ -490,8 +499,10 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
                     ol[i] = b;
                 }
                 if (live) {
-                    *reinterpret_cast<f32x4*>(yrow + 64 * j) = o0;
-                    *reinterpret_cast<f32x4*>(yrow + 64 * j + 4) = o1;
+                    if (p.y != nullptr) {
+                        *reinterpret_cast<f32x4*>(yrow + 64 * j) = o0;
+                        *reinterpret_cast<f32x4*>(yrow + 64 * j + 4) = o1;
+                    }
                     if (srow != nullptr) {
                         *reinterpret_cast<f16x8*>(srow + 64 * j) = oh;
                         *reinterpret_cast<f16x8*>(srow + FS_HID + 64 * j) = oh;
@@ -563,10 +574,11 @@ FsProfile g_fs_prof;
 
 }  // namespace
 
-extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
-                                           const void* d_wl, const float* d_b2, const float* d_residual,
-                                           const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
-                                           int32_t n, float* d_y, void* d_y_split, void* stream_) {
+namespace {
+int linear_ln_split_launch(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh, const void* d_wl,
+                           const float* d_b2, const float* d_residual, const void* d_residual_split, const float* d_gamma,
+                           const float* d_beta, float eps, int64_t m, int32_t k, int32_t n, float* d_y, void* d_y_split,
+                           void* stream_) {
     RAG_REQUIRE(n == FS_HID, RAG_ELIMIT, "rag_enc_linear_ln_split: the output width must be %d (got %d)", FS_HID, n);
     RAG_REQUIRE(k >= FS_C && k % FS_C == 0 && k <= FS_MAX_K, RAG_ELIMIT,
                 "rag_enc_linear_ln_split: the input width must be a multiple of %d up to %d (got %d)", FS_C, FS_MAX_K, k);
@@ -574,16 +586,19 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
     RAG_REQUIRE(in_is_split >= 0 && in_is_split <= 2, RAG_EINVAL, "rag_enc_linear_ln_split: in_is_split is 0, 1 or 2 (got %d)",
                 in_is_split);
     if (m == 0) return RAG_OK;
-    RAG_REQUIRE(d_in && d_wh && d_wl && d_b2 && d_residual && d_gamma && d_beta && d_y && (in_is_split || d_b1), RAG_EINVAL,
-                "rag_enc_linear_ln_split: null pointer");
+    RAG_REQUIRE(d_in && d_wh && d_wl && d_b2 && (d_residual || d_residual_split) && d_gamma && d_beta && (d_y || d_y_split) &&
+                (in_is_split || d_b1), RAG_EINVAL, "rag_enc_linear_ln_split: null pointer");
     RAG_REQUIRE(d_in != (const void*)d_y && d_in != d_y_split, RAG_EINVAL, "rag_enc_linear_ln_split: outputs must not alias the input");
-    RAG_REQUIRE(aligned16({d_in, d_b1, d_wh, d_wl, d_b2, d_residual, d_gamma, d_beta, d_y, d_y_split}), RAG_EINVAL,
+    RAG_REQUIRE(d_residual_split == nullptr || d_residual_split != d_y_split, RAG_EINVAL,
+                "rag_enc_linear_ln_split: the split output must not alias the split residual");
+    RAG_REQUIRE(aligned16({d_in, d_b1, d_wh, d_wl, d_b2, d_residual, d_residual_split, d_gamma, d_beta, d_y, d_y_split}), RAG_EINVAL,
                 "rag_enc_linear_ln_split: pointers must be 16-byte aligned");
     RAG_REQUIRE(ceil_div64(m, FS_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear_ln_split: too many rows");
     FfnOutParams p = {};
     if (in_is_split) p.hs = (const f16*)d_in; else p.h = (const float*)d_in;
     p.hs_hl = in_is_split == 2;
     p.b1 = d_b1; p.wh = (const f16*)d_wh; p.wl = (const f16*)d_wl; p.b2 = d_b2; p.residual = d_residual;
+    p.residual_s = (const f16*)d_residual_split;
     p.gamma = d_gamma; p.beta = d_beta; p.y = d_y; p.ys = (f16*)d_y_split; p.M = m; p.K = k; p.eps = eps;
     const size_t lds = (size_t)FS_OFF_B1 + 4 * ((size_t)k + 3 * FS_HID);
     hipStream_t stream = (hipStream_t)stream_;
@@ -604,6 +619,25 @@ extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split
         g_fs_prof.k[g_fs_prof.n++] = k;
     }
     return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
+                                           const void* d_wl, const float* d_b2, const float* d_residual,
+                                           const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
+                                           int32_t n, float* d_y, void* d_y_split, void* stream_) {
+    RAG_REQUIRE(m == 0 || d_residual, RAG_EINVAL, "rag_enc_linear_ln_split: null pointer");
+    return linear_ln_split_launch(d_in, in_is_split, d_b1, d_wh, d_wl, d_b2, d_residual, nullptr, d_gamma, d_beta, eps, m, k, n,
+                                  d_y, d_y_split, stream_);
+}
+
+extern "C" int rag_enc_linear_ln_split_chain_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
+                                                 const void* d_wl, const float* d_b2, const void* d_residual_split,
+                                                 const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
+                                                 int32_t n, float* d_y, void* d_y_split, void* stream_) {
+    RAG_REQUIRE(m == 0 || d_residual_split, RAG_EINVAL, "rag_enc_linear_ln_split_chain: null pointer");
+    return linear_ln_split_launch(d_in, in_is_split, d_b1, d_wh, d_wl, d_b2, nullptr, d_residual_split, d_gamma, d_beta, eps, m,
+                                  k, n, d_y, d_y_split, stream_);
 }
 
 extern "C" int rag_enc_linear_ln_split_pack_dev(const float* d_w, int32_t k, int32_t n, void* d_wh, void* d_wl, void* stream_) {

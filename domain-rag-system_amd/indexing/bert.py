@@ -292,6 +292,7 @@ class BertEncoder(nn.Module):
         fused_out = (self.fused_split_out and x.shape[0] >= int(os.environ.get('RAG_FUSED_OUT_MIN_TOKENS', '12288'))
                      and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, half)
                      and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, half))
+        chain = os.environ.get('RAG_CHAIN_RESIDUAL', '1') != '0'
         # (the library's GEMM tiles are 256 columns wide: [T, 1152] pads its last tile by half, [T, 768] + [T, 384] ran
         # 3-4 ms of 277 faster on 750 k tokens; 512 | 640 and three products of 384 were no faster, five of 256 slower)
         qkv_cuts = os.environ.get('RAG_QKV_SPLIT_N')
@@ -331,6 +332,18 @@ class BertEncoder(nn.Module):
                 if cls_only:
                     ctx = ctx[cu_seqlens[:-1].long()]
                 ctx3 = rag_hip.enc_split_bf16x3_dev(ctx, half)
+            if fused_out and chain:
+                # between the two fused kernels of a layer the residual stays in its split form: hi + lo of the [hi | hi | lo]
+                # row the first one writes anyway (the value the GEMM between them is given), so that one writes no fp32 row.
+                # (The output projection itself is faster with its residual as an fp32 row: 1.69 against 2.01 ms per 1 M
+                # tokens; the second product faster with the split one: 4.63 against 4.79.)
+                res = x[cu_seqlens[:-1].long()].contiguous() if cls_only else x
+                _, xs = rag_hip.enc_linear_ln_split_dev(ctx3, None, *self._weight_halves(l.attn_out), l.attn_out.bias, res,
+                                                        l.attn_norm.weight, l.attn_norm.bias, l.attn_norm.eps, want_y=False)
+                x, xs = rag_hip.enc_linear_ln_split_dev(mm(xs, l.ffn_in), l.ffn_in.bias, *self._weight_halves(l.ffn_out),
+                                                        l.ffn_out.bias, xs, l.ffn_norm.weight, l.ffn_norm.bias,
+                                                        l.ffn_norm.eps, want_split=li != last)
+                continue
             if cls_only:
                 x = x[cu_seqlens[:-1].long()].contiguous()
             if fused_out:

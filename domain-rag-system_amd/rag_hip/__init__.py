@@ -99,6 +99,7 @@ SIGNATURES = {
                                       _i32, _vp, _vp, _vp, _vp]),
     'rag_enc_add_layernorm_dev': (_i32, [_vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp]),
     'rag_enc_linear_ln_split_dev': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'rag_enc_linear_ln_split_chain_dev': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i64, _i32, _i32, _vp, _vp, _vp]),
     'rag_enc_linear_ln_split_pack_dev': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
     'rag_enc_linear_ln_split_profile': (_i32, [_i32]),
     'rag_enc_linear_ln_split_profile_read': (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_i32)]),
@@ -1106,11 +1107,12 @@ def enc_linear_ln_split_supported(k, n, half):
     return n == 384 and k % 32 == 0 and 32 <= k <= 2048 and half == torch.float16
 
 
-def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, want_split=True):
+def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, want_split=True, want_y=True):
     """LayerNorm(residual + a @ W.T + b2) * gamma + beta at fp32 precision on the fp16 matrix cores
     (rag_enc_linear_ln_split_dev).  x_in fp32 [M, K] with b1: a = GELU(x_in + b1); x_in fp16 [M, 3K] = [hi | hi | lo]
-    or [M, 2K] = [hi | lo] (b1 None): a is that split operand.  wh, wl: split_weight_halves(W), W [384, K].  Returns
-    (y fp32 [M, 384], its fp16 [hi | hi | lo] split [M, 1152] or None)."""
+    or [M, 2K] = [hi | lo] (b1 None): a is that split operand.  wh, wl: split_weight_halves(W), W [384, K].
+    residual: fp32 [M, 384], or fp16 [M, 1152] = the split a previous call returned (rag_enc_linear_ln_split_chain_dev).
+    Returns (y fp32 [M, 384] or None, its fp16 [hi | hi | lo] split [M, 1152] or None)."""
     import torch
     m = x_in.shape[0]
     n, k = wh.shape
@@ -1121,19 +1123,25 @@ def enc_linear_ln_split_dev(x_in, b1, wh, wl, b2, residual, gamma, beta, eps, wa
         raise ValueError("x_in must be fp32 [M, K] or fp16 [M, 3K] or [M, 2K]")
     if not is_split and (b1 is None or tuple(b1.shape) != (k,)):
         raise ValueError("an fp32 input needs its bias b1 [K]")
-    if tuple(wl.shape) != (n, k) or tuple(residual.shape) != (m, n):
-        raise ValueError("wl must have the shape of wh and residual must be [M, N]")
+    chain = residual.dtype == torch.float16
+    if tuple(wl.shape) != (n, k) or tuple(residual.shape) != (m, 3 * n if chain else n):
+        raise ValueError("wl must have the shape of wh and residual must be fp32 [M, N] or fp16 [M, 3N]")
+    if not chain and residual.dtype != torch.float32:
+        raise ValueError("residual must be fp32 [M, N] or fp16 [M, 3N]")
+    if not want_y and not want_split:
+        raise ValueError("want_y=False needs want_split")
     for v in (b2, gamma, beta):
         if tuple(v.shape) != (n,):
             raise ValueError("b2, gamma and beta must be [N]")
-    y = torch.empty((m, n), dtype=torch.float32, device=x_in.device)
+    y = torch.empty((m, n), dtype=torch.float32, device=x_in.device) if want_y else None
     ys = torch.empty((m, 3 * n), dtype=torch.float16, device=x_in.device) if want_split else None
     f32 = torch.float32
-    check(lib().rag_enc_linear_ln_split_dev(_ptr(x_in), int(is_split), None if is_split else _ptr(b1, f32),
-                                            _ptr(wh, torch.float16), _ptr(wl, torch.float16), _ptr(b2, f32),
-                                            _ptr(residual, f32), _ptr(gamma, f32), _ptr(beta, f32), float(eps), m, k, n,
-                                            _ptr(y), _ptr(ys) if ys is not None else None, _stream()),
-          'rag_enc_linear_ln_split_dev')
+    name = 'rag_enc_linear_ln_split_chain_dev' if chain else 'rag_enc_linear_ln_split_dev'
+    check(getattr(lib(), name)(_ptr(x_in), int(is_split), None if is_split else _ptr(b1, f32),
+                               _ptr(wh, torch.float16), _ptr(wl, torch.float16), _ptr(b2, f32),
+                               _ptr(residual, torch.float16 if chain else f32), _ptr(gamma, f32), _ptr(beta, f32), float(eps),
+                               m, k, n, _ptr(y) if y is not None else None, _ptr(ys) if ys is not None else None, _stream()),
+          name)
     return y, ys
 
 

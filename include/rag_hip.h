@@ -460,11 +460,20 @@ int rag_enc_bias_add_layernorm_split_dev(const float* d_y, const float* d_bias, 
  * weight: the kernel streams them chunk by chunk).  The product is hi.hi + lo.hi + hi.lo with fp32
  * accumulation; bias, residual and LayerNorm are fp32.  d_y_split (may be NULL): fp16 [m][1152] rows
  * [hi | hi | lo] of y, the operand of the next split-precision GEMM.  k a multiple of 32 up to 2048;
- * outputs must not alias the input; residual may alias y.                                          */
+ * outputs must not alias the input; residual may alias y.  d_y may be NULL when d_y_split is not (only the
+ * split row is wanted: the fp32 row's stores are 9 % of a call with k = 384).                      */
 int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
                                 const void* d_wl, const float* d_b2, const float* d_residual,
                                 const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
                                 int32_t n, float* d_y, void* d_y_split, void* stream);
+/* The same for a chain of these calls: the residual comes as d_residual_split = fp16 [m][1152] rows [hi | hi | lo]
+ * (the d_y_split of the call that produced it; residual = hi + lo, which carries 22 of its 24 significant bits
+ * - the same value the GEMMs between the calls are given), so that the producing call needs to write no fp32
+ * row.  d_y_split must not alias d_residual_split.                                                       */
+int rag_enc_linear_ln_split_chain_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
+                                      const void* d_wl, const float* d_b2, const void* d_residual_split,
+                                      const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,
+                                      int32_t n, float* d_y, void* d_y_split, void* stream);
 /* The weight operands of rag_enc_linear_ln_split_dev from W fp32 [n = 384][k] row-major (a Linear layer's weight as
  * transformers stores it): d_wh, d_wl each 384 * k fp16, where 16-byte piece 1536 c + 4 f + j holds columns
  * 32 c + 8 (j ^ ((f >> 2) & 3)) + 0..7 of row (f with bits 2 and 3 swapped): every 32-column chunk contiguous

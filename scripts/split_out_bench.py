@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--k', type=int, default=1536, help='input width: 1536 = second feed-forward product, 384 = output projection')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--abl', default=None, help='comma list of RAG_FS_ABL masks to time (library built with -DFS_STAMPS=1)')
+    ap.add_argument('--forms', action='store_true', help='time the residual / output forms of both operand sources and stop')
     ap.add_argument('--only', default=None, choices=['fused', 'fused-split'],
                     help='run only the fused kernel, fp32 input or pre-split input (profiler passes)')
     args = ap.parse_args()
@@ -80,6 +81,22 @@ def main():
                 s0 = stamps()
                 ms1 = timed(lambda: rag_hip.enc_linear_ln_split_dev(a3, None, wh, wl, b2, res, gamma, beta, 1e-12))
                 print(f'abl {mask:>3}: fp32-in {ms0:.3f} ms [{s0}]   split-in {ms1:.3f} ms [{stamps()}]', flush=True)
+        return
+    if args.forms:
+        a3 = rag_hip.enc_split_bf16x3_dev(h, f16)
+        a2 = torch.cat([a3[:, :k], a3[:, 2 * k:]], dim=1).contiguous()
+        r3 = rag_hip.enc_split_bf16x3_dev(res, f16)
+        fn = rag_hip.enc_linear_ln_split_dev
+        with torch.no_grad():
+            for name, src, bias in (('fp32 in, GELU', h, b1), ('[hi|hi|lo] in', a3, None), ('[hi|lo] in', a2, None)):
+                t0 = timed(lambda: fn(src, bias, wh, wl, b2, res, gamma, beta, 1e-12))
+                t1 = timed(lambda: fn(src, bias, wh, wl, b2, r3, gamma, beta, 1e-12))
+                t2 = timed(lambda: fn(src, bias, wh, wl, b2, r3, gamma, beta, 1e-12, want_y=False))
+                t3 = timed(lambda: fn(src, bias, wh, wl, b2, res, gamma, beta, 1e-12, want_split=False))
+                t4 = timed(lambda: fn(src, bias, wh, wl, b2, res, gamma, beta, 1e-12, want_y=False))
+                print(f'k={k} {name:14s}: fp32 residual, y + split {t0:.3f} ms | split residual, y + split {t1:.3f} | '
+                      f'split residual, split only {t2:.3f} | fp32 residual, y only {t3:.3f} | fp32 residual, split only {t4:.3f}',
+                      flush=True)
         return
     if args.only == 'fused-split':
         a3 = rag_hip.enc_split_bf16x3_dev(h, torch.float16)

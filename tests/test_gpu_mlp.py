@@ -216,6 +216,20 @@ def test_linear_ln_split_matches_float64(m, k):
     a2 = torch.cat([a3[:, :k], a3[:, 2 * k:]], dim=1).contiguous()
     y4, s4 = rag_hip.enc_linear_ln_split_dev(a2, None, wh, wl, b2, res, gamma, beta, 1e-12)
     assert torch.equal(y4, y3) and torch.equal(s4, _)
+    # chained form (rag_enc_linear_ln_split_chain_dev): the residual given as the [hi | hi | lo] rows of a previous
+    # call; equals the fp32-residual call on the residual hi + lo bit for bit, with and without the fp32 row
+    r3 = rag_hip.enc_split_bf16x3_dev(res, torch.float16)
+    r_back = r3[:, :384].float() + r3[:, 768:].float()
+    assert float((r_back - res).abs().max()) <= 2 ** -22 * float(res.abs().max())
+    y5, s5 = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, r_back, gamma, beta, 1e-12)
+    y6, s6 = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, r3, gamma, beta, 1e-12)
+    none7, s7 = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, r3, gamma, beta, 1e-12, want_y=False)
+    assert torch.equal(y6, y5) and torch.equal(s6, s5) and none7 is None and torch.equal(s7, s5)
+    assert float((y6.double() - want).abs().max()) < max(3 * err_plain, 2e-6)
+    none8, s8 = rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12, want_y=False)
+    assert none8 is None and torch.equal(s8, ys)
+    with pytest.raises(ValueError):
+        rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res, gamma, beta, 1e-12, want_y=False, want_split=False)
     # the separate route it replaces: library GEMM on [hi|hi|lo] operands + bias/residual/LayerNorm kernel
     w3 = rag_hip.split_weight_bf16x3(w, torch.float16)
     sep, _ = rag_hip.enc_bias_add_layernorm_split_dev(torch.mm(a3, w3.t(), out_dtype=torch.float32), b2, res, gamma, beta,
@@ -244,6 +258,41 @@ def test_cross_encoder_fp32_forward_same_with_and_without_the_fused_output_kerne
         m.bert.fused_split_out = False
         b = m.forward_packed(ids, types, pos, cu, int(lens.max()))
     assert float((a - b).abs().max()) < 1e-6
+
+
+def test_cross_encoder_fp32_forward_with_the_residual_kept_split(monkeypatch):
+    """Between the two fused kernels of a layer the fused route keeps the residual as the [hi | hi | lo] row the first
+    one writes (22 of an fp32 row's 24 bits) instead of an fp32 row beside it: logits against the fp32-residual route
+    and against a float64 forward of the same weights."""
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    m, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                                split_dtype=torch.float16)
+    plain, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32)
+    g = torch.Generator(device=dev).manual_seed(6)
+    lens = torch.randint(5, 150, (300,), generator=g, device=dev, dtype=torch.int32)
+    cu = torch.zeros((301,), dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    t = int(cu[-1])
+    assert t >= 12288
+    ids = torch.randint(1000, cfg.vocab_size, (t,), generator=g, device=dev, dtype=torch.int32)
+    types = torch.zeros_like(ids)
+    pos = torch.cat([torch.arange(int(n), dtype=torch.int32, device=dev) for n in lens])
+    with torch.no_grad():
+        a = m.forward_packed(ids, types, pos, cu, int(lens.max())).clone()
+        monkeypatch.setenv('RAG_CHAIN_RESIDUAL', '0')
+        b = m.forward_packed(ids, types, pos, cu, int(lens.max())).clone()
+        ids_l = [ids[int(cu[i]):int(cu[i + 1])].tolist() for i in range(300)]
+        it, mt = bert.pad_batch(ids_l, 0, dev)
+        plain64 = plain.double()
+        want = plain64(it, torch.zeros_like(it), mt).float()
+        plain32 = plain64.float()
+        ref32 = plain32(it, torch.zeros_like(it), mt)
+    err_chain, err_fp32res = float((a - want).abs().max()), float((b - want).abs().max())
+    err_torch = float((ref32 - want).abs().max())
+    print(f'max logit error vs float64: split residual {err_chain:.2e}, fp32 residual {err_fp32res:.2e}, PyTorch fp32 {err_torch:.2e}')
+    assert float((a - b).abs().max()) < 2e-6
+    assert err_chain < max(3 * err_torch, 2e-6)
 
 
 def test_linear_ln_split_argument_errors_and_row_independence():
