@@ -403,19 +403,16 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
     const float* b2s = vec + p.K + 8 * l8;
     const float* gs = b2s + FS_HID;
     const float* bs = gs + FS_HID;
-    f32x4 rs[12];                                             // residual of the pass ahead
+    // residual of the pass ahead, as loaded: 8 floats, or (split residual) 8 high halves and 8 low halves; turned into
+    // floats where it is used, so that the loads are nothing but loads and are all in flight at once
+    f32x4 rs[12];
     auto load_residual = [&](int64_t tok) {
-        if (p.residual_s != nullptr) {                        // fp16 halves of the row: hi + lo is exact in fp32
+        if (p.residual_s != nullptr) {
             const f16* res = p.residual_s + min(tok, p.M - 1) * (3 * FS_HID) + 8 * l8;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const f16x8 a = *reinterpret_cast<const f16x8*>(res + 64 * j);
-                const f16x8 b = *reinterpret_cast<const f16x8*>(res + 2 * FS_HID + 64 * j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    rs[2 * j][i] = (float)a[i] + (float)b[i];
-                    rs[2 * j + 1][i] = (float)a[4 + i] + (float)b[4 + i];
-                }
+                rs[2 * j] = *reinterpret_cast<const f32x4*>(res + 64 * j);
+                rs[2 * j + 1] = *reinterpret_cast<const f32x4*>(res + 2 * FS_HID + 64 * j);
             }
         } else {
             const float* res = p.residual + min(tok, p.M - 1) * FS_HID + 8 * l8;
@@ -458,10 +455,19 @@ __global__ __launch_bounds__(FS_NT, 1) void ffn_out_split_kernel(FfnOutParams p)
                 const f32x4 y1 = *reinterpret_cast<const f32x4*>(trow + 64 * j + 4);
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2s + 64 * j);
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(b2s + 64 * j + 4);
+                f32x4 r0 = rs[2 * j], r1 = rs[2 * j + 1];
+                if (p.residual_s != nullptr) {                // hi + lo: exact in fp32
+                    const f16x8 a = __builtin_bit_cast(f16x8, rs[2 * j]), b = __builtin_bit_cast(f16x8, rs[2 * j + 1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        r0[i] = (float)a[i] + (float)b[i];
+                        r1[i] = (float)a[4 + i] + (float)b[4 + i];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[8 * j + i] = (y0[i] + c0[i]) + rs[2 * j][i];
-                    v[8 * j + 4 + i] = (y1[i] + c1[i]) + rs[2 * j + 1][i];
+                    v[8 * j + i] = (y0[i] + c0[i]) + r0[i];
+                    v[8 * j + 4 + i] = (y1[i] + c1[i]) + r1[i];
                     sum += v[8 * j + i];
                     sum += v[8 * j + 4 + i];
                 }

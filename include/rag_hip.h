@@ -469,7 +469,7 @@ int rag_enc_linear_ln_split_dev(const void* d_in, int32_t in_is_split, const flo
 /* The same for a chain of these calls: the residual comes as d_residual_split = fp16 [m][1152] rows [hi | hi | lo]
  * (the d_y_split of the call that produced it; residual = hi + lo, which carries 22 of its 24 significant bits
  * - the same value the GEMMs between the calls are given), so that the producing call needs to write no fp32
- * row.  d_y_split must not alias d_residual_split.                                                       */
+ * row (d_y NULL there and here; d_y_split may then not be NULL).  d_y_split must not alias d_residual_split. */
 int rag_enc_linear_ln_split_chain_dev(const void* d_in, int32_t in_is_split, const float* d_b1, const void* d_wh,
                                       const void* d_wl, const float* d_b2, const void* d_residual_split,
                                       const float* d_gamma, const float* d_beta, float eps, int64_t m, int32_t k,

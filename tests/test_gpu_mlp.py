@@ -261,9 +261,9 @@ def test_cross_encoder_fp32_forward_same_with_and_without_the_fused_output_kerne
 
 
 def test_cross_encoder_fp32_forward_with_the_residual_kept_split(monkeypatch):
-    """Between the two fused kernels of a layer the fused route keeps the residual as the [hi | hi | lo] row the first
-    one writes (22 of an fp32 row's 24 bits) instead of an fp32 row beside it: logits against the fp32-residual route
-    and against a float64 forward of the same weights."""
+    """The fused route keeps the residual stream as the [hi | hi | lo] rows its kernels write (22 of an fp32 row's 24
+    bits) instead of an fp32 row beside them: logits against the fp32-residual route and against a float64 forward of
+    the same weights."""
     from indexing import bert
     dev = torch.device('cuda:0')
     m, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
