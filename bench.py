@@ -431,14 +431,16 @@ def main():
     # in its feed-forward form (K = intermediate size): LayerNorm(residual + GELU(h + b1) W2^T + b2) with its
     # split output.  Algorithmic work of a launch over `rows` tokens: 2 * rows * K * hidden FLOPs (the kernel
     # executes three fp16 MFMA products per algorithmic one: priced against the fp16 matrix peak, executed rate
-    # beside it) and rows * (4 K + 4 hidden [residual] + 4 hidden [y] + 6 hidden [y as fp16 hi | hi | lo]) bytes.
+    # beside it) and rows * (4 K + 4 hidden [residual: the hi and lo halves of a split row] + 6 hidden [y as fp16
+    # hi | hi | lo]) bytes; 4 hidden more with RAG_CHAIN_RESIDUAL=0, where an fp32 row is written as well.
     if roofline_ff is None and len(lls_ms):
         hid, inter = ce_cfg.hidden_size, ce_cfg.intermediate_size
         sel = lls_k == inter
         if sel.any():
             f_rows, f_s = float(lls_rows[sel].sum()), float(lls_ms[sel].sum()) / 1e3
             f_flops = 2.0 * f_rows * inter * hid
-            f_bytes = f_rows * (4.0 * inter + 14.0 * hid)
+            y_row = 0.0 if os.environ.get('RAG_CHAIN_RESIDUAL', '1') != '0' else 4.0
+            f_bytes = f_rows * (4.0 * inter + (10.0 + y_row) * hid)
             roofline_ff = {'kernel': 'ffn_out_split_kernel<0> (second feed-forward product + bias + GELU + residual + LayerNorm + split, '
                                      'fp32-equivalent on fp16 MFMA)',
                            'bound': 'mfma', 'achieved': round(f_flops / f_s / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
@@ -458,8 +460,8 @@ def main():
                 o_rows, o_s = float(lls_rows[~sel].sum()), float(lls_ms[~sel].sum()) / 1e3
                 roofline_ff['attention_output_form'] = {
                     'ms_per_step': round(o_s * 1e3 / max(args.steps, 1), 2),
-                    'algorithmic_gbs': round(o_rows * 18.0 * hid / o_s / 1e9, 1),
-                    'hbm_frac': round(o_rows * 18.0 * hid / o_s / 1e9 / HBM_PEAK_GBS, 4),
+                    'algorithmic_gbs': round(o_rows * (14.0 + y_row) * hid / o_s / 1e9, 1),
+                    'hbm_frac': round(o_rows * (14.0 + y_row) * hid / o_s / 1e9 / HBM_PEAK_GBS, 4),
                     'executed_tflops': round(6.0 * o_rows * hid * hid / o_s / 1e12, 1)}
             ff_pmc = os.path.join(ROOT, 'profiles', 'pmc_linear_ln_split.json')
             if os.path.exists(ff_pmc):

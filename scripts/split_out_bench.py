@@ -23,7 +23,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--abl', default=None, help='comma list of RAG_FS_ABL masks to time (library built with -DFS_STAMPS=1)')
     ap.add_argument('--forms', action='store_true', help='time the residual / output forms of both operand sources and stop')
-    ap.add_argument('--only', default=None, choices=['fused', 'fused-split'],
+    ap.add_argument('--only', default=None, choices=['fused', 'fused-split', 'fused-chain'],
                     help='run only the fused kernel, fp32 input or pre-split input (profiler passes)')
     args = ap.parse_args()
     import rag_hip
@@ -97,6 +97,13 @@ def main():
                 print(f'k={k} {name:14s}: fp32 residual, y + split {t0:.3f} ms | split residual, y + split {t1:.3f} | '
                       f'split residual, split only {t2:.3f} | fp32 residual, y only {t3:.3f} | fp32 residual, split only {t4:.3f}',
                       flush=True)
+        return
+    if args.only == 'fused-chain':      # the form a layer of the cross-encoder runs: fp32 in + GELU, residual = a split row, split row out
+        r3 = rag_hip.enc_split_bf16x3_dev(res, f16)
+        with torch.no_grad():
+            ms = timed(lambda: rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, r3, gamma, beta, 1e-12, want_y=False))
+        print(f'fused (fp32 in, GELU; split residual, split out): tokens={m} k={k} {ms:.3f} ms  {3 * flops / ms / 1e9:.0f} TFLOP/s executed',
+              flush=True)
         return
     if args.only == 'fused-split':
         a3 = rag_hip.enc_split_bf16x3_dev(h, torch.float16)
