@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const int32_t* __r
             Vec8<T>::load(beta + ch * 8, b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
-            Vec8<T>::store(out + t * H + ch * 8, y);
+            if (out != nullptr) Vec8<T>::store(out + t * H + ch * 8, y);
             if constexpr (std::is_same<T, float>::value) {
                 if (split != nullptr) {
                     typename Half16<SPLIT>::x8 hi, lo;
@@ -1103,7 +1103,7 @@ int embed_layernorm_launch(const int32_t* d_ids, const int32_t* d_types, const i
     RAG_REQUIRE(d_out_split == nullptr || (dtype == RAG_DTYPE_F32 && (half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16)),
                 RAG_EINVAL, "rag_enc_embed_layernorm_split: fp32 tables and bf16 or fp16 halves");
     if (n_tokens == 0) return RAG_OK;
-    RAG_REQUIRE(d_ids && d_pos && d_word && d_position && d_type_emb && d_gamma && d_beta && d_out, RAG_EINVAL,
+    RAG_REQUIRE(d_ids && d_pos && d_word && d_position && d_type_emb && d_gamma && d_beta && (d_out || d_out_split), RAG_EINVAL,
                 "rag_enc_embed_layernorm: null pointer");
     RAG_REQUIRE((n_tokens + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_embed_layernorm: too many tokens");
     hipStream_t stream = (hipStream_t)stream_;

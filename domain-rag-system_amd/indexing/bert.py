@@ -171,9 +171,12 @@ class BertEncoder(nn.Module):
                              f"sequences up to {rag_hip.ENC_MAX_SEQ} tokens")
         if self.split_gemm and self.fused_split_tails and self.word.weight.dtype == torch.float32:
             # embedding + LayerNorm + the split for the first GEMM in one pass
+            # (where the layers keep the residual stream in the split rows, nothing reads the fp32 row)
+            fused_out, chain = self._fused_route(ids.shape[0])
             x, xs = rag_hip.enc_embed_layernorm_split_dev(ids, types, pos, self.word.weight, self.position.weight,
                                                           self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
-                                                          self.emb_norm.eps, self.split_dtype)
+                                                          self.emb_norm.eps, self.split_dtype,
+                                                          want_out=not (fused_out and chain))
             return self._forward_packed_split(x, cu_seqlens, max_seq_len, first_token_only, xs)
         x = rag_hip.enc_embed_layernorm_dev(ids, types, pos, self.word.weight, self.position.weight,
                                             self.token_type.weight, self.emb_norm.weight, self.emb_norm.bias,
@@ -269,6 +272,19 @@ class BertEncoder(nn.Module):
             self._split_cache[key] = w
         return w
 
+    def _fused_route(self, n_tokens):
+        """(whether a batch of n_tokens runs its layers through the fused output kernels, whether those keep the residual
+        stream in the split rows)"""
+        import rag_hip
+        c = self.config
+        # (a 128-token tile of the fused output kernel takes ~100 us however empty the chip is: below ~96 tiles the
+        # library GEMM + tail kernels, which spread a small batch over the chip, are faster: 1.08 against 1.53 ms for
+        # one query's 50 pairs, equal at 14 k tokens, slower from there on)
+        fused_out = (self.fused_split_out and n_tokens >= int(os.environ.get('RAG_FUSED_OUT_MIN_TOKENS', '12288'))
+                     and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, self.split_dtype)
+                     and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, self.split_dtype))
+        return fused_out, os.environ.get('RAG_CHAIN_RESIDUAL', '1') != '0'
+
     def _forward_packed_split(self, x, cu_seqlens, max_seq_len, first_token_only=False, xs=None):
         """The fp32 layers with every GEMM as a split-bf16 product (see _linear_split) and the work between
         two GEMMs in one kernel each: bias + residual + LayerNorm + split of the result, bias + GELU + split.
@@ -286,13 +302,7 @@ class BertEncoder(nn.Module):
         head_dim = self.config.hidden_size // self.config.num_attention_heads
         mfma_attn = self.split_attention and rag_hip.enc_attention_split_supported(head_dim, max_seq_len)
         c = self.config
-        # (a 128-token tile of the fused output kernel takes ~100 us however empty the chip is: below ~96 tiles the
-        # library GEMM + tail kernels, which spread a small batch over the chip, are faster: 1.08 against 1.53 ms for
-        # one query's 50 pairs, equal at 14 k tokens, slower from there on)
-        fused_out = (self.fused_split_out and x.shape[0] >= int(os.environ.get('RAG_FUSED_OUT_MIN_TOKENS', '12288'))
-                     and rag_hip.enc_linear_ln_split_supported(c.hidden_size, c.hidden_size, half)
-                     and rag_hip.enc_linear_ln_split_supported(c.intermediate_size, c.hidden_size, half))
-        chain = os.environ.get('RAG_CHAIN_RESIDUAL', '1') != '0'
+        fused_out, chain = self._fused_route(xs.shape[0])       # (x is None where nothing reads the fp32 rows)
         # (the library's GEMM tiles are 256 columns wide: [T, 1152] pads its last tile by half, [T, 768] + [T, 384] ran
         # 3-4 ms of 277 faster on 750 k tokens; 512 | 640 and three products of 384 were no faster, five of 256 slower)
         qkv_cuts = os.environ.get('RAG_QKV_SPLIT_N')

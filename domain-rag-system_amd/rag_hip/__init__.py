@@ -795,9 +795,9 @@ def enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, be
     return out
 
 
-def enc_embed_layernorm_split_dev(ids, types, pos, word, position, type_emb, gamma, beta, eps, half=None):
+def enc_embed_layernorm_split_dev(ids, types, pos, word, position, type_emb, gamma, beta, eps, half=None, want_out=True):
     """enc_embed_layernorm_dev for float32 tables that also returns the rows split for the first split-precision GEMM
-    (rag_enc_embed_layernorm_split_dev): (out fp32 [T, H], [T, 3H] = [hi | hi | lo] in `half`)."""
+    (rag_enc_embed_layernorm_split_dev): (out fp32 [T, H] or None, [T, 3H] = [hi | hi | lo] in `half`)."""
     import torch
     t = ids.shape[0]
     hidden = word.shape[1]
@@ -806,7 +806,7 @@ def enc_embed_layernorm_split_dev(ids, types, pos, word, position, type_emb, gam
     if tuple(pos.shape) != (t,) or (types is not None and tuple(types.shape) != (t,)):
         raise ValueError("ids, types and pos must have one entry per token")
     code, hdt = _half_code(half)
-    out = torch.empty((t, hidden), dtype=torch.float32, device=ids.device)
+    out = torch.empty((t, hidden), dtype=torch.float32, device=ids.device) if want_out else None
     split = torch.empty((t, 3 * hidden), dtype=hdt, device=ids.device)
     f32 = torch.float32
     check(lib().rag_enc_embed_layernorm_split_dev(_ptr(ids, torch.int32), _ptr(types, torch.int32), _ptr(pos, torch.int32),

@@ -496,7 +496,8 @@ int rag_enc_embed_layernorm_dev(const int32_t* d_ids, const int32_t* d_types, co
  * [n_tokens][3 * hidden], what rag_enc_split_bf16x3_dev makes of `out`): the embedding output of
  * transformers' BertEmbeddings as the left operand of the first split-precision GEMM, in one pass
  * (reached through CrossEncoder.predict / SentenceTransformer.encode, reference
- * src/reranker/rerank.py:79-84, src/indexing/embedder.py:65-71).                                  */
+ * src/reranker/rerank.py:79-84, src/indexing/embedder.py:65-71).  d_out may be NULL: only the split row is
+ * written (what a layer made of rag_enc_linear_ln_split_chain_dev calls reads).                    */
 int rag_enc_embed_layernorm_split_dev(const int32_t* d_ids, const int32_t* d_types, const int32_t* d_pos,
                                       const float* d_word, const float* d_position, const float* d_type_emb,
                                       const float* d_gamma, const float* d_beta, float eps, int64_t n_tokens,
