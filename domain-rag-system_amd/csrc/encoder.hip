@@ -335,7 +335,15 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
     typedef typename Half16<H16>::x8 hx8;
     typedef typename Half16<H16>::x4 hx4;
     typedef typename Half16<H16>::x2 hx2;
-    constexpr int KROW = D + 8;
+    // Head size 32: both images in 64-byte rows [key][32] with nothing between them (256 bytes of LDS per key for the four
+    // images: a workgroup more per CU than padded rows allow).  Keys: the 16-byte piece p of row `key` sits at
+    // p ^ ((key >> 2) & 3), so that 16 consecutive rows read at one piece index cover all 64 banks once.  Values stay
+    // row-major too and the V^T operand comes out of that image through the transposing LDS read (ds_read_b64_tr_b16:
+    // a 16-lane group reads a block of 4 keys x 16 dimensions, each lane receives one dimension's 4 keys; with 64-byte
+    // rows the four groups' blocks tile the 64 banks exactly), so staging writes 16-byte pieces instead of transposing
+    // through 4-byte ones.  Head size 64: keys in rows padded by 8, values transposed [dimension][key] in rows of kpad + 4.
+    constexpr bool TR = D == 32;
+    constexpr int KROW = TR ? D : D + 8;
     constexpr int DT = D / 32;
     constexpr int KC = D / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -358,11 +366,11 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
     const size_t otok = out_hl ? (size_t)2 * H : tok;     // output row: [hi | lo] or [hi | hi | lo]
     H16* obase = (first_only ? out + (size_t)seq * otok : out + (size_t)first * otok) + head * D;
     const int kpad = (len + 31) & ~31;
-    const int VROW = kpad + 4;
+    const int VROW = TR ? D : kpad + 4;
     H16* Kh = reinterpret_cast<H16*>(smem);
     H16* Kl = Kh + (size_t)kpad * KROW;
     H16* Vh = Kl + (size_t)kpad * KROW;
-    H16* Vl = Vh + (size_t)D * VROW;
+    H16* Vl = Vh + (TR ? (size_t)kpad * D : (size_t)D * VROW);
     const int n_query_rows = first_only ? min(1, len) : len;
 
     // eight consecutive fp32 values (+ bias) -> bf16 high and low parts
@@ -400,20 +408,37 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
         load8(p + 2 * H, bv, key < len, v0h, v0l);
         load8(p + tok + H, bk, key + 1 < len, k1h, k1l);
         load8(p + tok + 2 * H, bv, key + 1 < len, v1h, v1l);
-        *reinterpret_cast<hx8*>(Kh + key * KROW + c8 * 8) = k0h;
-        *reinterpret_cast<hx8*>(Kl + key * KROW + c8 * 8) = k0l;
-        *reinterpret_cast<hx8*>(Kh + (key + 1) * KROW + c8 * 8) = k1h;
-        *reinterpret_cast<hx8*>(Kl + (key + 1) * KROW + c8 * 8) = k1l;
+        const int kc = TR ? (c8 ^ ((key >> 2) & 3)) * 8 : c8 * 8;       // (key and key + 1 share key >> 2: key is even)
+        *reinterpret_cast<hx8*>(Kh + key * KROW + kc) = k0h;
+        *reinterpret_cast<hx8*>(Kl + key * KROW + kc) = k0l;
+        *reinterpret_cast<hx8*>(Kh + (key + 1) * KROW + kc) = k1h;
+        *reinterpret_cast<hx8*>(Kl + (key + 1) * KROW + kc) = k1l;
+        if constexpr (TR) {
+            *reinterpret_cast<hx8*>(Vh + key * D + c8 * 8) = v0h;
+            *reinterpret_cast<hx8*>(Vl + key * D + c8 * 8) = v0l;
+            *reinterpret_cast<hx8*>(Vh + (key + 1) * D + c8 * 8) = v1h;
+            *reinterpret_cast<hx8*>(Vl + (key + 1) * D + c8 * 8) = v1l;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            hx2 ph, pl;
-            ph[0] = v0h[j]; ph[1] = v1h[j];
-            pl[0] = v0l[j]; pl[1] = v1l[j];
-            *reinterpret_cast<hx2*>(Vh + (c8 * 8 + j) * VROW + key) = ph;
-            *reinterpret_cast<hx2*>(Vl + (c8 * 8 + j) * VROW + key) = pl;
+            for (int j = 0; j < 8; ++j) {
+                hx2 ph, pl;
+                ph[0] = v0h[j]; ph[1] = v1h[j];
+                pl[0] = v0l[j]; pl[1] = v1l[j];
+                *reinterpret_cast<hx2*>(Vh + (c8 * 8 + j) * VROW + key) = ph;
+                *reinterpret_cast<hx2*>(Vl + (c8 * 8 + j) * VROW + key) = pl;
+            }
         }
     }
     __syncthreads();
+    // transposing read: lane 4q + p of a 16-lane group g addresses row q, dimensions 4p.. of its group's block and
+    // receives dimension (lane % 16) of rows 0..3: with blocks at dimensions 16 (g & 1) and keys 4 (g >> 1) that is the
+    // operand layout of the other form (dimension r = lane % 32, keys 4h .. 4h + 3)
+    typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+    const int tr_off = ((lane & 15) >> 2) * D + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto tr_read = [](const H16* p) {
+        return __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(p)));
+    };
+    const int k_swz = TR ? (r >> 2) & 3 : 0;                  // (kb is a multiple of 32: (kb + r) >> 2 and r >> 2 agree mod 4)
 
     for (int qb = wave; qb * 32 < n_query_rows; qb += (int)(blockDim.x >> 6)) {
         const int q = qb * 32 + r;
@@ -431,8 +456,9 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                const hx8 ah = *reinterpret_cast<const hx8*>(Kh + (kb + r) * KROW + 16 * c + 8 * h);
-                const hx8 al = *reinterpret_cast<const hx8*>(Kl + (kb + r) * KROW + 16 * c + 8 * h);
+                const int kc = TR ? ((2 * c + h) ^ k_swz) * 8 : 16 * c + 8 * h;
+                const hx8 ah = *reinterpret_cast<const hx8*>(Kh + (kb + r) * KROW + kc);
+                const hx8 al = *reinterpret_cast<const hx8*>(Kl + (kb + r) * KROW + kc);
                 s = Half16<H16>::mfma(al, qh[c], s);
                 s = Half16<H16>::mfma(ah, ql[c], s);
                 s = Half16<H16>::mfma(ah, qh[c], s);
@@ -483,9 +509,16 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const size_t vo = (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
-                    const hx4 h0 = *reinterpret_cast<const hx4*>(Vh + vo), h1 = *reinterpret_cast<const hx4*>(Vh + vo + 8);
-                    const hx4 l0 = *reinterpret_cast<const hx4*>(Vl + vo), l1 = *reinterpret_cast<const hx4*>(Vl + vo + 8);
+                    hx4 h0, h1, l0, l1;
+                    if constexpr (TR) {
+                        const int vo = (kb + 16 * t + 4 * h) * D + tr_off;
+                        h0 = tr_read(Vh + vo); h1 = tr_read(Vh + vo + 8 * D);
+                        l0 = tr_read(Vl + vo); l1 = tr_read(Vl + vo + 8 * D);
+                    } else {
+                        const size_t vo = (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
+                        h0 = *reinterpret_cast<const hx4*>(Vh + vo); h1 = *reinterpret_cast<const hx4*>(Vh + vo + 8);
+                        l0 = *reinterpret_cast<const hx4*>(Vl + vo); l1 = *reinterpret_cast<const hx4*>(Vl + vo + 8);
+                    }
                     hx8 avh, avl;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { avh[j] = h0[j]; avh[4 + j] = h1[j]; avl[j] = l0[j]; avl[4 + j] = l1[j]; }
@@ -979,7 +1012,8 @@ int attention_split_launch(const float* d_qkv, const float* d_bias, const int32_
                 reinterpret_cast<uintptr_t>(d_out) % 16 == 0, RAG_EINVAL, "rag_enc_attention_split: pointers must be 16-byte aligned");
     RAG_REQUIRE(((int64_t)n_seq + 8) * n_heads < (1ll << 31), RAG_ELIMIT, "rag_enc_attention_split: too many (sequence, head) pairs");
     const int kpad = (max_seq_len + 31) & ~31;
-    const size_t lds = 2 * ((size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2);
+    const size_t lds = head_dim == 32 ? (size_t)kpad * 256         // four images of 64-byte rows
+                                      : 2 * ((size_t)kpad * (head_dim + 8) * 2 + (size_t)head_dim * (kpad + 4) * 2);
     RAG_REQUIRE(lds <= 160 * 1024, RAG_ELIMIT, "rag_enc_attention_split: sequences of %d tokens with head size %d need %zu bytes of LDS",
                 max_seq_len, head_dim, lds);
     const float scale = 1.4426950408889634f / sqrtf((float)head_dim);

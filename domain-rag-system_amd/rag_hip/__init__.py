@@ -928,6 +928,8 @@ def enc_attention_split_supported(head_dim, max_seq_len):
     if head_dim not in (32, 64) or max_seq_len > ENC_MAX_SEQ:
         return False
     kpad = (int(max_seq_len) + 31) // 32 * 32
+    if head_dim == 32:
+        return kpad * 256 <= 160 * 1024
     return 2 * (kpad * (head_dim + 8) * 2 + head_dim * (kpad + 4) * 2) <= 160 * 1024
 
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--mean', type=float, default=45.0)
     ap.add_argument('--clip', type=int, default=0, help='cut every sequence to this many tokens')
+    ap.add_argument('--hi-lo', action='store_true', help='[hi | lo] output rows (rag_enc_attention_split_hl_dev)')
     ap.add_argument('--lds-for', type=int, default=0, help='size the LDS image for this sequence length (>= the longest)')
     args = ap.parse_args()
     import rag_hip
@@ -40,7 +41,7 @@ def main():
     bias = torch.randn((3 * 384,), device=dev) * 0.1
     longest = max(int(lens.max()), args.lds_for)
     for first in (False,):
-        fn = lambda: rag_hip.enc_attention_split_dev(qkv, bias, cu, longest, 12, first_only=first, half=torch.float16)
+        fn = lambda: rag_hip.enc_attention_split_dev(qkv, bias, cu, longest, 12, first_only=first, half=torch.float16, hi_lo=args.hi_lo)
         fn(); fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
