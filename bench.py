@@ -6,17 +6,24 @@ embed -> dense kNN -> BM25 -> RRF -> cross-encoder rerank -> top-k, everything r
 in HBM when the timed region starts.  Prints ONE JSON line (rank 0).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W         (starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 With N > 1 the corpus rows are sharded (each rank holds --rows rows: weak scaling in corpus
-size) and a step is one batch of --batch x N queries: every rank searches its rows for all of
-them, the per-shard top-k lists are all-gathered over RCCL and merged, and the cross-encoder
-pairs are split across the ranks (--batch x rerank_top_n pairs per GPU whatever N is).
+size; the default is 1.25 M rows per rank, so that N = 8 is the 10 M-row configuration, and
+1 M rows at N = 1) and a step is one batch of --batch x N queries: every rank searches its rows
+for all of them, the per-shard top-k lists are all-gathered over RCCL and merged, and the
+cross-encoder pairs are split across the ranks (--batch x rerank_top_n pairs per GPU whatever N
+is).  Started without a rank environment and with --gpus N > 1, the script launches N fresh rank
+processes of itself (torch.distributed.run) before it makes any GPU call, hands rank 0's JSON
+line through on stdout and exits with the launcher's status.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,7 +47,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=1024,
                     help='queries per step and GPU: a step is one batch of batch x N queries (every rank searches its rows for all\n'
                          'of them and reranks 1/N of the pairs, so the rerank work per GPU stays fixed as N grows)')
-    ap.add_argument('--rows', type=int, default=1_000_000, help='corpus rows per GPU')
+    ap.add_argument('--rows', type=int, default=None,
+                    help='corpus rows per GPU (default: 1,000,000 on one GPU, 1,250,000 per GPU on several: 10 M rows on eight)')
     ap.add_argument('--dim', type=int, default=768)
     ap.add_argument('--vocab', type=int, default=200_000)
     ap.add_argument('--top-k', type=int, default=5)
@@ -81,11 +89,41 @@ def parse():
     ap.add_argument('--cpu-queries', type=int, default=32,
                     help='queries timed on the host for cpu_baseline (0 = skip); 32 are 10-15 s of work on 16 cores')
     ap.add_argument('--stage-times', action='store_true', help='extra untimed pass with per-stage events')
-    return ap.parse_args()
+    args = ap.parse_args()
+    return args
+
+
+def default_rows(world):
+    """Rows per GPU when --rows is not given: the 1M-row configuration on one GPU, 1.25 M per GPU on several
+    (eight GPUs hold the 10M-row configuration)."""
+    return 1_000_000 if world == 1 else 1_250_000
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started by hand (no rank environment): run N fresh rank processes of this script under
+    torch.distributed.run and pass rank 0's line through.  Called before this process has made any GPU call (it never
+    makes one: the ranks are children, and this process only waits for them)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % args.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.environ.get('RAG_BENCH_ENTRY', os.path.abspath(__file__))] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 1) // max(args.gpus, 1)))))
+    log('[launcher] ' + ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def token_id_limit(args):
+    """Synthetic token ids are drawn below the smaller of the two models' vocabularies (30522 for the named ones)."""
+    from indexing import bert
+    return min(bert.ARCHS[args.embed_arch].vocab_size, bert.ARCHS[args.ce_arch].vocab_size)
 
 
 def build_shard(args, rank, world, dev, dist):
@@ -123,7 +161,7 @@ def build_shard(args, rank, world, dev, dist):
     clen = torch.from_numpy(ln + 2).to(dev)
     off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(clen, 0)
-    tok = torch.randint(1000, 30522, (int(off[-1]),), generator=g, device=dev, dtype=torch.int32)
+    tok = torch.randint(1000, token_id_limit(args), (int(off[-1]),), generator=g, device=dev, dtype=torch.int32)
     if dist is not None:                # replicate the token store (small) so any rank can pack any pair
         lens = [torch.empty_like(clen) for _ in range(world)]
         dist.all_gather(lens, clen)
@@ -162,7 +200,7 @@ def make_queries(args, n_batches, dev, seed=99):
         mask = np.zeros((b, smax), np.int64)
         ce_tok, ce_off = [], [0]
         for i in range(b):
-            body = rng.integers(1000, 30522, size=int(qlen[i]))
+            body = rng.integers(1000, token_id_limit(args), size=int(qlen[i]))
             ids[i, 0], ids[i, 1:1 + qlen[i]], ids[i, 1 + qlen[i]] = 101, body, 102
             mask[i, :qlen[i] + 2] = 1
             ce_tok.append(body)
@@ -242,12 +280,22 @@ def cpu_baseline(args, searcher_models, rows_dev, host, queries, gpu_out):
 
 def main():
     args = parse()
+    if 'RANK' not in os.environ and (args.gpus > 1 or os.environ.get('RAG_DIST_FORCE') == '1'):
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        log(f'[bench] --gpus {args.gpus} but the launcher started {world} rank(s): running {world}')
+    if args.rows is None:
+        args.rows = default_rows(world)
     batch_per_gpu = args.batch
     args.batch = batch_per_gpu * world             # the step's batch: every rank sees all of its queries
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # RAG_BENCH_DEVICE=cpu: the host side of this script (launcher, shard build with global statistics, exchanges, the
+    # line) on the CPU over gloo.  The GPU entry points of rag_hip must have been replaced by the caller (the CPU tests
+    # do that with their doubles, tests/bench_double.py); nothing this mode prints is a measurement.
+    on_cpu = os.environ.get('RAG_BENCH_DEVICE') == 'cpu'
     # rehearsal of the multi-rank code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
     rehearse = world > 1 and os.environ.get('RAG_BENCH_REHEARSE') == '1'
     if rehearse:
@@ -259,8 +307,9 @@ def main():
     force = os.environ.get('RAG_DIST_FORCE') == '1' and 'RANK' in os.environ
     if world > 1 or force:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        if rehearse:
+        if not on_cpu:
+            torch.cuda.set_device(local)
+        if rehearse or on_cpu:
             dist.init_process_group('gloo')
         else:
             # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one
@@ -276,26 +325,32 @@ def main():
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
+    dev = torch.device('cpu') if on_cpu else torch.device('cuda', local)
     import rag_hip
-    rag_hip.init(local)
+    if not on_cpu:
+        torch.cuda.set_device(dev)
+        rag_hip.init(local)
+    sync = (lambda: None) if on_cpu else torch.cuda.synchronize
     from indexing import bert
     from indexing.batch import BatchSearcher, TokenStore
 
     from indexing import gemm_tuning
     tuned = False
-    if args.tune_gemms:
+    if on_cpu:
+        pass
+    elif args.tune_gemms:
         tuned = gemm_tuning.enable(tune=True, table=args.tune_gemms)
     elif not args.no_gemm_table:
         tuned = gemm_tuning.enable(tune=False)
     log(f'[rank {rank}] hipBLASLt solution table: ' + ('tuning into ' + args.tune_gemms if args.tune_gemms
                                                       else 'in use' if tuned else 'not used'))
     rows, dense, bm25, tok, off, canon, host = build_shard(args, rank, world, dev, dist)
-    bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev, native=not args.embed_torch_ops,
-                               split_gemm=not args.embed_fp32_gemm)
+    bi, _, _ = bert.load_model('random:' + args.embed_arch, 'bi', dev, native=not (args.embed_torch_ops or on_cpu),
+                               split_gemm=not (args.embed_fp32_gemm or on_cpu))
     def load_ce(kind):
         """The cross-encoder in one of the three arithmetic forms of --ce-dtype."""
+        if on_cpu:
+            kind = 'fp32-torch'
         if kind == 'bf16':
             m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.bfloat16,
                                       native=not args.ce_torch_ops)
@@ -330,7 +385,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def as_args(q):
         return (q['ids'], q['mask'], q['qterms'], q['qoff'], q['n_terms'], q['ce_tok'], q['ce_off'])
@@ -344,30 +399,36 @@ def main():
 
     run(queries[:args.warmup])
     barrier()
-    dense.profile(True)
-    rag_hip.enc_mlp_profile(True)
-    rag_hip.enc_linear_ln_split_profile(True)
+    if not on_cpu:
+        dense.profile(True)
+        rag_hip.enc_mlp_profile(True)
+        rag_hip.enc_linear_ln_split_profile(True)
     t0 = time.perf_counter()
     out = run(queries[args.warmup:args.warmup + args.steps])[-1]
     barrier()
     dt = time.perf_counter() - t0
-    scan_ms = dense.profile_read()
-    dense.profile(False)
-    mlp_ms, mlp_rows = rag_hip.enc_mlp_profile_read()
-    rag_hip.enc_mlp_profile(False)
-    lls_ms, lls_rows, lls_k = rag_hip.enc_linear_ln_split_profile_read()
-    rag_hip.enc_linear_ln_split_profile(False)
+    scan_ms = mlp_ms = lls_ms = np.zeros(0, np.float32)
+    mlp_rows = lls_rows = lls_k = np.zeros(0, np.int64)
+    if not on_cpu:
+        scan_ms = dense.profile_read()
+        dense.profile(False)
+        mlp_ms, mlp_rows = rag_hip.enc_mlp_profile_read()
+        rag_hip.enc_mlp_profile(False)
+        lls_ms, lls_rows, lls_k = rag_hip.enc_linear_ln_split_profile_read()
+        rag_hip.enc_linear_ln_split_profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
 
     # per-stage breakdown (untimed extra pass with a sync after every stage)
-    searcher.timing = True
-    step(queries[0])
-    torch.cuda.synchronize()
-    searcher.timing = False
-    stage_ms = {k: round(v, 3) for k, v in searcher.times.as_dict().items()}
+    stage_ms = {}
+    if not on_cpu:
+        searcher.timing = True
+        step(queries[0])
+        torch.cuda.synchronize()
+        searcher.timing = False
+        stage_ms = {k: round(v, 3) for k, v in searcher.times.as_dict().items()}
 
     if rank != 0:
         if dist is not None:
@@ -381,31 +442,34 @@ def main():
     # (one pass over the shard).  The split form runs three bf16 products per algorithmic one, so it is
     # priced against the bf16 matrix peak and its executed rate is given beside the algorithmic one; the
     # fp32 form is priced against the fp32 matrix peak.
-    flops = 2.0 * args.rows * args.dim * args.batch
-    scan_s = float(np.mean(scan_ms)) / 1e3 if len(scan_ms) else float('nan')
-    achieved = flops / scan_s / 1e12
-    dense_peak = MFMA_BF16_PEAK_TFLOPS if dense.split else MFMA_F32_PEAK_TFLOPS
-    roofline = {'kernel': '%s (%s)' % ('dense_scan_dma_kernel' if dense.split and args.batch >= 256 else 'dense_scan_kernel',
-                                       'split-bf16 products, fp32 accumulation' if dense.split else 'fp32'),
-                'bound': 'mfma', 'achieved': round(achieved, 2),
-                'peak': dense_peak, 'unit': 'TFLOP/s', 'frac': round(achieved / dense_peak, 4),
-                'traffic': None, 'avg_launch_ms': round(scan_s * 1e3, 3),
-                'algorithmic_gbs': round(4.0 * args.rows * args.dim / scan_s / 1e9, 1)}
-    if dense.split:
-        roofline['executed_tflops'] = round(3 * achieved, 1)
-        roofline['executed_frac'] = round(3 * achieved / dense_peak, 4)
-        roofline['vs_fp32_matrix_peak'] = round(achieved / MFMA_F32_PEAK_TFLOPS, 3)
-    # memory-side bytes of one launch from the PMC passes (FETCH_SIZE doubled as gfx950 needs,
-    # plus WRITE_SIZE), measured with scripts/kernel_bench.py on this workload and kept with
-    # the profiles; null when the workload differs from the one that was measured
-    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dense_scan.json')
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        w = pmc.get('workload', {})
-        if (w.get('rows'), w.get('dim'), w.get('batch'), w.get('k')) == (args.rows, args.dim, args.batch, 2 * t):
-            roofline['traffic'] = round(float(pmc['traffic_bytes_per_launch']) / 1e9, 2)
-            roofline['traffic_unit'] = 'GB per launch (rocprofv3 --pmc, separate passes)'
+    roofline = None
+    if len(scan_ms):
+        flops = 2.0 * args.rows * args.dim * args.batch
+        scan_s = float(np.mean(scan_ms)) / 1e3
+        achieved = flops / scan_s / 1e12
+        dense_split = bool(getattr(dense, 'split', False))
+        dense_peak = MFMA_BF16_PEAK_TFLOPS if dense_split else MFMA_F32_PEAK_TFLOPS
+        roofline = {'kernel': '%s (%s)' % ('dense_scan_dma_kernel' if dense_split and args.batch >= 256 else 'dense_scan_kernel',
+                                           'split-bf16 products, fp32 accumulation' if dense_split else 'fp32'),
+                    'bound': 'mfma', 'achieved': round(achieved, 2),
+                    'peak': dense_peak, 'unit': 'TFLOP/s', 'frac': round(achieved / dense_peak, 4),
+                    'traffic': None, 'avg_launch_ms': round(scan_s * 1e3, 3),
+                    'algorithmic_gbs': round(4.0 * args.rows * args.dim / scan_s / 1e9, 1)}
+        if dense_split:
+            roofline['executed_tflops'] = round(3 * achieved, 1)
+            roofline['executed_frac'] = round(3 * achieved / dense_peak, 4)
+            roofline['vs_fp32_matrix_peak'] = round(achieved / MFMA_F32_PEAK_TFLOPS, 3)
+        # memory-side bytes of one launch from the PMC passes (FETCH_SIZE doubled as gfx950 needs,
+        # plus WRITE_SIZE), measured with scripts/kernel_bench.py on this workload and kept with
+        # the profiles; null when the workload differs from the one that was measured
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_dense_scan.json')
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            w = pmc.get('workload', {})
+            if (w.get('rows'), w.get('dim'), w.get('batch'), w.get('k')) == (args.rows, args.dim, args.batch, 2 * t):
+                roofline['traffic'] = round(float(pmc['traffic_bytes_per_launch']) / 1e9, 2)
+                roofline['traffic_unit'] = 'GB per launch (rocprofv3 --pmc, separate passes)'
 
     # the kernel with the largest share of a step: the cross-encoder's feed-forward block.  Algorithmic
     # work of a launch: 4 * rows * hidden * intermediate FLOPs (two products), 2 * rows * hidden * 2 bytes.
@@ -473,7 +537,9 @@ def main():
 
     result = {
         'metric': 'queries/sec end-to-end (embed+kNN+BM25+RRF+rerank) @ Recall@5, 1M x 768 corpus',
-        'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec', 'n_gpus': world,
+        'value': round(args.batch * args.steps / dt, 2), 'unit': 'queries/sec',
+        'n_gpus': dist.get_world_size() if dist is not None else 1,
+        'rccl_ranks': dist.get_world_size() if (dist is not None and dist.get_backend() == 'nccl') else 0,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s / %s' % (
@@ -484,8 +550,8 @@ def main():
             'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else
             'f32 embedder forward with GEMMs as 3 split-bf16 MFMA products, fp32 accumulation (cosine within 1e-5 of fp32)'),
         'data': 'synthetic (seeded random unit vectors, Zipf postings, random token ids, random-init weights)',
-        'config': {'workload': '%dM x %d corpus%s, hybrid vector+BM25, RRF, MiniLM-L6 cross-encoder rerank_top_n=%d, '
-                               'top_k=%d' % (n_total // 1_000_000, args.dim,
+        'config': {'workload': '%s x %d corpus%s, hybrid vector+BM25, RRF, MiniLM-L6 cross-encoder rerank_top_n=%d, '
+                               'top_k=%d' % (('%gM' % (n_total / 1e6)) if n_total >= 1_000_000 else '%d rows' % n_total, args.dim,
                                              ' row-sharded %d ways' % world if world > 1 else '', t, args.top_k),
                    'rows_per_gpu': args.rows, 'rows_total': n_total, 'dim': args.dim, 'batch': args.batch,
                    'batch_per_gpu': batch_per_gpu, 'global_batch': args.batch,

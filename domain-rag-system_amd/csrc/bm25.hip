@@ -310,6 +310,7 @@ struct rag_bm25_s {
     double* idf = nullptr;
     bool owns = false;
     int64_t n_docs = 0, vocab = 0, nnz = 0, row_base = 0;
+    int device = 0;                     // the device the postings live on (current device at create)
     DevBuf toff, tau, cand_key, cand_row, cand_count;
 };
 
@@ -331,7 +332,10 @@ extern "C" int rag_bm25_create(const int64_t* indptr, const uint32_t* rows, cons
     }
     RAG_REQUIRE(nnz >= 0 && nnz < (1ll << 32), RAG_ELIMIT, "rag_bm25_create: %lld postings out of range", (long long)nnz);
     RAG_REQUIRE(nnz == 0 || (rows && impact), RAG_EINVAL, "rag_bm25_create: null postings");
+    int device = 0;
+    RAG_HIP_TRY(hipGetDevice(&device));
     rag_bm25_s* h = new rag_bm25_s();
+    h->device = device;
     h->n_docs = n_docs;
     h->vocab = vocab;
     h->nnz = nnz;
@@ -554,9 +558,10 @@ extern "C" int rag_bm25_reserve(rag_bm25_t h, int32_t max_queries, int32_t max_t
 // The work buffers live in a file-scope device array instead of the handle's grow-only buffers: nothing in
 // this entry point calls hipMalloc / hipFree or any routine that does.  Each GPU the library runs on holds
 // its own copy of the array, at its own address, until the process ends; the address is looked up once per
-// device (rag_bm25_static_setup, called by rag_init and, failing that, by the first call on a device).
-// Every call on a GPU uses that GPU's one array: two calls that overlap on one GPU (two streams, two
-// threads) race.  The array keeps the last call's contents; the thresholds and list counters, which must
+// device (rag_bm25_static_setup, called by rag_init; without rag_init on the device the entry point refuses).
+// Every call on a GPU uses that GPU's one array: calls from different streams or threads are chained on the
+// device with an event (created by rag_init), so they run one after the other; only replays of captured graphs
+// that overlap other searches on the same GPU can still race.  The array keeps the last call's contents; the thresholds and list counters, which must
 // start at zero, are cleared by every call.
 constexpr size_t BM_STATIC_BYTES = 32u << 20;
 static __device__ __align__(256) unsigned char scratch[BM_STATIC_BYTES];
@@ -565,6 +570,8 @@ namespace {
 constexpr int BM_MAX_DEVICES = 64;
 std::mutex g_static_mu;
 unsigned char* g_static_ptr[BM_MAX_DEVICES] = {};   // device address of `scratch` on each device
+hipEvent_t g_static_done[BM_MAX_DEVICES] = {};      // recorded behind the last search that used the device's array
+bool g_static_used[BM_MAX_DEVICES] = {};
 }  // namespace
 
 // Look up this device's address of the static work array (the array's name itself is only a host-side
@@ -578,6 +585,9 @@ int rag_bm25_static_setup() {
         unsigned char* ptr = nullptr;
         RAG_HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
         RAG_REQUIRE(ptr != nullptr, RAG_EHIP, "hipGetSymbolAddress returned a null address for the static work array");
+        hipEvent_t ev = nullptr;
+        RAG_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_static_done[dev] = ev;
         g_static_ptr[dev] = ptr;
     }
     return RAG_OK;
@@ -605,19 +615,35 @@ extern "C" int rag_bm25_search_static_dev(rag_bm25_t h, const int32_t* d_qterms,
     int dev = 0;
     RAG_HIP_TRY(hipGetDevice(&dev));
     RAG_REQUIRE(dev >= 0 && dev < BM_MAX_DEVICES, RAG_ELIMIT, "device index %d beyond %d", dev, BM_MAX_DEVICES);
+    RAG_REQUIRE(dev == h->device, RAG_EINVAL,
+                "rag_bm25_search_static_dev: the index lives on device %d, the current device is %d (each GPU has its own "
+                "work array)", h->device, dev);
     unsigned char* ptr;
     {
         std::lock_guard<std::mutex> lock(g_static_mu);
         ptr = g_static_ptr[dev];
     }
-    if (ptr == nullptr) {                       // rag_init was not called for this device
-        if ((rc = rag_bm25_static_setup())) return rc;
-        std::lock_guard<std::mutex> lock(g_static_mu);
-        ptr = g_static_ptr[dev];
-    }
+    // rag_init(device) looks up the array's address and allocates the device's fault word; doing either here would be
+    // the allocation (and the synchronous call) this entry point promises never to make
+    RAG_REQUIRE(ptr != nullptr && rag_fault_word_ready(), RAG_EINVAL,
+                "rag_bm25_search_static_dev: call rag_init(%d) first (it sets up this device's static work array and "
+                "fault word; this entry point allocates nothing)", dev);
     const Bm25Work w = {(uint32_t*)(ptr + o_toff), (unsigned long long*)(ptr + o_tau), (uint64_t*)(ptr + o_key),
                         (uint32_t*)(ptr + o_row), (int32_t*)(ptr + o_cnt)};
-    return bm25_search_on(h, w, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count, stream);
+    // Calls on different streams (or threads) share the device's one array: each search first waits, on the device,
+    // for the search before it, and leaves an event behind its own kernels.  The lock covers wait + launches + record,
+    // so the chain is the order in which the calls took it.  A capturing stream is left alone (an event recorded
+    // outside the capture cannot be waited for inside it): a captured search is ordered by its graph, and replays that
+    // overlap other searches on the same GPU remain the caller's to serialise.
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    const bool chained = !rag_stream_capturing(stream);
+    if (chained && g_static_used[dev]) RAG_HIP_TRY(hipStreamWaitEvent(stream, g_static_done[dev], 0));
+    rc = bm25_search_on(h, w, d_qterms, d_qoff, n_queries, n_terms_total, k, d_out_score, d_out_row, d_out_count, stream);
+    if (chained) {
+        RAG_HIP_TRY(hipEventRecord(g_static_done[dev], stream));
+        g_static_used[dev] = true;
+    }
+    return rc;
 }
 
 #define BM_TRY_OR_CLEAN(expr)                                                                    \

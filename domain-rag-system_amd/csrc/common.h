@@ -78,6 +78,7 @@ int rag_grant_dyn_lds(const void* kernel, size_t bytes);
 // device data outside its array sets a bit there and carries on with a safe value instead
 // of making the access.
 uint32_t* rag_fault_word();
+bool rag_fault_word_ready();
 
 // a stream under graph capture records no timing events (an event recorded into a graph cannot be read back)
 static inline bool rag_stream_capturing(hipStream_t stream) {

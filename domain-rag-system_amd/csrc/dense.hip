@@ -1215,18 +1215,20 @@ extern "C" int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max
     RAG_REQUIRE(max_queries >= 1 && max_k >= 1 && max_k <= RAG_MAX_K, RAG_ELIMIT,
                 "rag_dense_reserve: need max_queries >= 1 and 1 <= max_k <= %d (got %d, %d)", RAG_MAX_K, max_queries, max_k);
     if (h->n_rows == 0) return RAG_OK;
-    // every tile configuration a batch of up to max_queries can run (the work buffers are sized by the configuration)
-    const int sizes[] = {1, 32, 64, 128, 255, max_queries, -128, -255, -max_queries};      // negative: the pre-pass of that batch
-    for (int nqs : sizes) {
-        const int nq = nqs < 0 ? -nqs : nqs;
-        if (nq > max_queries) continue;
+    // Every plan a batch of up to max_queries can run.  The work buffers are sized by the plan, and a plan's sizes are
+    // not monotone in the batch size (strips are rounded per query-block count), so every query-block count of every
+    // tile configuration is planned: batch sizes at both sides of every multiple of 32 (the smallest query block),
+    // each as the main pass and as both forms of the pre-pass (group maxima; lists, which a row mask asks for).
+    const int64_t sample = prepass_rows(max_k, h->n_rows);
+    auto plan = [&](int nq, int64_t n_rows, int maxima) -> int {
         DenseScanParams p = {};
-        p.n_rows = nqs < 0 ? (prepass_rows(max_k, h->n_rows) < h->n_rows ? prepass_rows(max_k, h->n_rows) : h->n_rows) : h->n_rows;
-        p.maxima = nqs < 0;
+        p.n_rows = n_rows;
+        p.maxima = maxima;
         p.n_queries = nq;
         p.k = max_k;
+        p.kpub = max_k;
         p.cap = dense_cap(max_k);
-        int rc = dense_dispatch(nq, h->rows_split != nullptr, [&](auto cfg) -> int {
+        return dense_dispatch(nq, h->rows_split != nullptr, [&](auto cfg) -> int {
             constexpr int C = decltype(cfg)::value;
             if constexpr (C == 0) return plan_scan<1, 1, 4, 1>(h, p);
             else if constexpr (C == 1) return plan_scan<1, 2, 4, 1>(h, p);
@@ -1236,6 +1238,20 @@ extern "C" int rag_dense_reserve(rag_dense_t h, int32_t max_queries, int32_t max
                 return rc3 ? rc3 : plan_scan<4, 2, 2, 2>(h, p);
             }
         });
+    };
+    auto plan_batch = [&](int nq) -> int {
+        if (nq < 1 || nq > max_queries) return RAG_OK;
+        int rc = plan(nq, h->n_rows, 0);
+        if (!rc && prepass_wanted(nq, h->n_rows, sample)) {
+            rc = plan(nq, sample, 1);
+            if (!rc) rc = plan(nq, sample, 0);
+        }
+        return rc;
+    };
+    for (int nq = 32; nq <= max_queries + 31; nq += 32) {
+        int rc = plan_batch(nq < max_queries ? nq : max_queries);
+        if (!rc) rc = plan_batch(nq - 31);           // first batch size of this query-block count
+        if (!rc) rc = plan_batch(nq + 1);
         if (rc) return rc;
     }
     int rc;

@@ -673,6 +673,14 @@ uint32_t* rag_fault_word() {
     return g_fault[dev];
 }
 
+// whether the current device's fault word exists already (never allocates)
+bool rag_fault_word_ready() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return false;
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    return g_fault[dev] != nullptr;
+}
+
 // dynamic-LDS grants, per (device, kernel)
 namespace {
 struct LdsGrant { const void* fn; size_t bytes; };

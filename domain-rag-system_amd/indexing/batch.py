@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 import rag_hip
-from .bert import Graphed as _Graphed
+from .bert import GraphCache as _GraphCache
 
 
 @dataclass
@@ -122,7 +122,8 @@ class BatchSearcher:
         off = os.environ.get('RAG_GRAPHS') == '0'
         self.graph_max_batch = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH', '32'))
         self.graph_max_batch_ce = 0 if off else int(os.environ.get('RAG_GRAPH_MAX_BATCH_CE', '4'))
-        self._graphs = {}
+        # (bounded: every entry keeps the private memory pool of one captured forward alive; oldest dropped first)
+        self._graphs = _GraphCache(limit=int(os.environ.get('RAG_GRAPH_CACHE', '32')))
 
     # the reference's candidate arithmetic (scripts/query.py:139, hybrid_indexer.py:83,90)
     @property
@@ -191,17 +192,7 @@ class BatchSearcher:
 
     def _graphed(self, key, fn, inputs):
         """The captured form of fn for this key (shapes), or None when capture failed once (then never tried again)."""
-        g = self._graphs.get(key)
-        if g is None and key not in self._graphs:
-            try:
-                g = _Graphed(fn, inputs)
-            except Exception as e:                       # noqa: BLE001 - any capture problem: run eagerly from now on
-                import warnings
-                warnings.warn(f"HIP graph capture of {key[0]} failed ({type(e).__name__}: {e}); running it eagerly")
-                torch.cuda.synchronize()
-                g = None
-            self._graphs[key] = g
-        return g
+        return self._graphs.get(key, fn, inputs)
 
     def _embed_local(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         bert = self.bi_encoder.bert
@@ -234,16 +225,18 @@ class BatchSearcher:
             return score, row, cnt
         b = score.shape[0]
         kk = score.shape[1]
-        # outputs are the ranks' tensors concatenated along dim 0: [world * B, k]
-        gs = torch.empty((self.world * b, kk), dtype=score.dtype, device=score.device)
-        gr = torch.empty((self.world * b, kk), dtype=row.dtype, device=row.device)
-        gc = torch.empty((self.world * b,), dtype=cnt.dtype, device=cnt.device)
-        self._all_gather(gs, score)
-        self._all_gather(gr, row)
-        self._all_gather(gc, cnt)
-        return rag_hip.merge_topk_dev(gs.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
-                                      gr.view(self.world, b, kk).permute(1, 0, 2).contiguous(),
-                                      gc.view(self.world, b).t().contiguous(), k, smaller_is_better=smaller_is_better)
+        # one exchange per list: scores, rows and counts of a query travel as one row of bytes
+        # ([B, kk * (score bytes + 8) + 4]); the gathered tensor is the ranks' pieces along dim 0: [world * B, bytes]
+        parts = [score.contiguous(), row.contiguous(), cnt.contiguous().reshape(b, 1)]
+        widths = [p.shape[1] * p.element_size() for p in parts]
+        mine = torch.cat([p.view(torch.uint8).reshape(b, w) for p, w in zip(parts, widths)], dim=1)
+        gathered = torch.empty((self.world * b, mine.shape[1]), dtype=torch.uint8, device=mine.device)
+        self._all_gather(gathered, mine)
+        gathered = gathered.view(self.world, b, -1).permute(1, 0, 2)           # [B, world, bytes]
+        cuts = [0, widths[0], widths[0] + widths[1], sum(widths)]
+        gs, gr, gc = (gathered[:, :, lo:hi].contiguous().view(p.dtype)
+                      for lo, hi, p in zip(cuts[:-1], cuts[1:], parts))
+        return rag_hip.merge_topk_dev(gs, gr, gc.reshape(b, self.world), k, smaller_is_better=smaller_is_better)
 
     def dense_search(self, qvec: torch.Tensor, k: int):
         s, r, c = self.dense.search_dev(qvec, k)
@@ -318,7 +311,9 @@ class BatchSearcher:
         total, longest = (int(v) for v in torch.stack([plen.sum(), plen.max()]).cpu().tolist())
         if longest <= 0:
             return False
-        t_pad = (total + 2047) // 2048 * 2048
+        # at least one token beyond the stream: a trailing empty slot (fused row -1, no tokens) starts AT the stream's
+        # end, and the forward reads the first row of every sequence
+        t_pad = (total + 2048) // 2048 * 2048
         max_len = min(self.ce_max_len, (longest + 63) // 64 * 64)
         q_cap = (max(int(q_tok.shape[0]), 1) + 64 * b - 1) // (64 * b) * (64 * b)
         pair_query = my_q
@@ -333,7 +328,8 @@ class BatchSearcher:
             return self.cross_encoder.forward_packed(ids, types, pos, cu, max_len)
         qt = torch.zeros((q_cap,), dtype=torch.int32, device=q_tok.device)
         qt[:q_tok.shape[0]] = q_tok
-        g = self._graphed(('rerank', b, n, t_pad, max_len, q_cap, id(store)), fwd, [qt, q_off, my_r])
+        g = self._graphed(('rerank', b, n, t_pad, max_len, q_cap, store), fwd, [qt, q_off, my_r])     # (the key holds the store itself:
+        #                                                             an id() could be a freed store's, reused)
         if g is None:
             return False
         logits_mine[:n] = g(qt, q_off, my_r)

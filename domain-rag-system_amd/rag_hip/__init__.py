@@ -504,7 +504,8 @@ class Bm25Index:
     def search_static_dev(self, qterms, qoff, n_terms_total, k, out):
         """search_dev without any device allocation (rag_bm25_search_static_dev): the work buffers come from a
         static device array, so `out` = (scores [B,k] f64, rows [B,k] i64, counts [B] i32) must be given and
-        sizes beyond the array's capacity raise (RAG_ELIMIT).  Calls on one GPU must not overlap."""
+        sizes beyond the array's capacity raise (RAG_ELIMIT).  Needs rag_init on the device; calls from different streams
+        are chained on the device (they share the GPU's one array)."""
         import torch
         b = qoff.shape[0] - 1
         score, row, cnt = out

@@ -204,10 +204,14 @@ int rag_bm25_search(rag_bm25_t h, const int32_t* qterms, const int32_t* qoff, in
  * and document tile, per-query thresholds, candidate lists) come from a static device array of
  * rag_bm25_search_static_capacity() bytes (32 MiB) that every GPU the library runs on holds until the
  * process ends, instead of the handle's grow-only buffers: the call never reaches hipMalloc or hipFree.
+ * Precondition: rag_init(device) has run for the index's device, which must be the current device (rag_init
+ * looks up that device's address of the array and allocates its fault word); otherwise RAG_EINVAL.
  * A search that needs more than the array holds returns RAG_ELIMIT and leaves the outputs untouched; the
  * need is about  n_queries * ceil(n_docs / 2048) * k * 12  +  n_terms_total * (ceil(n_docs / 2048) + 1) * 4
  * bytes (1M documents, k = 100: up to 55 queries per call).  All calls on one GPU share that GPU's
- * array: calls that overlap on one GPU race, so serialise them (one stream, or events between streams). */
+ * array: calls issued on different streams or threads are chained on the device (each waits for the one
+ * before it through an event), so they do not race; a call on a capturing stream is not chained, and graph
+ * replays that overlap other searches on the same GPU race unless the caller serialises them.           */
 int64_t rag_bm25_search_static_capacity(void);
 int rag_bm25_search_static_dev(rag_bm25_t h, const int32_t* d_qterms, const int32_t* d_qoff,
                                int32_t n_queries, int32_t n_terms_total, int32_t k,

@@ -63,6 +63,9 @@ class DenseIndex:
                     out[i, j] = np.float32(self.rows[r - self.row_base] @ q[i])
         return out
 
+    def reserve(self, max_queries, k):
+        pass
+
     def profile(self, enable=True):
         pass
 
@@ -116,6 +119,9 @@ class Bm25Index:
             row[i, :len(order)] = order + self.row_base
             score[i, :len(order)] = s[order]
         return score, row, cnt
+
+    def reserve(self, max_queries, max_terms_total, k):
+        pass
 
     def search_dev(self, qterms, qoff, n_terms_total, k, out=None):
         t, o = qterms.numpy(), qoff.numpy()
@@ -272,12 +278,25 @@ def check_faults():
     """The doubles index nothing with unchecked device data: nothing to report."""
 
 
-def install(monkeypatch):
-    """Replace the GPU entry points of the imported ``rag_hip`` module with the doubles."""
+DOUBLES = ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
+           'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev',
+           'RowFilter', 'check_faults')
+
+
+class _Setter:
+    """monkeypatch-shaped setter for processes that are not pytest (a rank of a launched script)."""
+
+    @staticmethod
+    def setattr(obj, name, value):
+        setattr(obj, name, value)
+
+
+def install(monkeypatch=None):
+    """Replace the GPU entry points of the imported ``rag_hip`` module with the doubles (for good when no
+    monkeypatch fixture is given)."""
     import rag_hip
-    for name in ('DenseIndex', 'Bm25Index', 'fuse_rrf', 'fuse_weighted', 'fuse_rrf_dev', 'fuse_weighted_dev',
-                 'topk_segmented', 'topk_segmented_dev', 'topk_stable_f64', 'merge_topk_dev', 'ce_pair_len_dev', 'ce_pack_dev',
-                 'RowFilter', 'check_faults'):
+    monkeypatch = monkeypatch or _Setter
+    for name in DOUBLES:
         monkeypatch.setattr(rag_hip, name, globals()[name])
     # the device-side index build is replaced by the host counting it is tested against on the GPU
     from indexing import bm25_indexer

@@ -74,9 +74,9 @@ def test_graph_replay_equals_the_eager_path(b, monkeypatch):
         assert float((a['logits'] - e['logits']).abs().max()) < 2e-6        # same kernels on the same rows of a longer stream
         assert torch.equal(a['rows'], e['rows']) and torch.equal(a['count'], e['count'])
     # both forwards really came from captured graphs, one per shape
-    kinds = sorted(k[0] for k, g in graphed._graphs.items() if g is not None)
+    kinds = sorted(k[0] for k, g in graphed._graphs.graphs.items() if g is not None)
     assert 'embed' in kinds and 'rerank' in kinds
-    assert not eager._graphs
+    assert not eager._graphs.graphs
     # the static packing is the boolean-mask packing
     ids, mask = q[0], q[1]
     p_ids, p_types, p_pos, cu, longest = w['bi'].bert.pack(ids, mask)
@@ -86,6 +86,57 @@ def test_graph_replay_equals_the_eager_path(b, monkeypatch):
     assert int(s_ids[n:].abs().sum()) == 0
     w['dense'].close()
     w['bm25'].close()
+
+
+def test_graphed_rerank_with_empty_trailing_slots_on_a_full_token_grid(monkeypatch):
+    """A pool shorter than rerank_top_n leaves trailing slots without tokens (fused row -1); when the live pairs fill the
+    2048-token grid exactly, those slots start AT the end of the stream.  The captured forward must still have a row
+    there to read: same logits as the eager route, no device-side fault."""
+    from indexing import bert
+    from indexing.batch import BatchSearcher, TokenStore
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    ce, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, native=True, split_gemm=True,
+                               split_dtype=torch.float16)
+    rng = np.random.default_rng(61)
+    q_len, t = 10, 20
+    clen = np.asarray([107] * 16 + [115] + [40] * 8)                      # pairs of 120 x 16 + 128 = 2048 tokens
+    off = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+    tok = torch.from_numpy(rng.integers(1000, 30522, size=int(off[-1])).astype(np.int32)).to(dev)
+    store = TokenStore(tok, torch.from_numpy(off).to(dev), 0)
+    q_tok = torch.from_numpy(rng.integers(1000, 30522, size=q_len).astype(np.int32)).to(dev)
+    q_off = torch.tensor([0, q_len], dtype=torch.int64, device=dev)
+    fused_row = torch.full((1, t), -1, dtype=torch.int64, device=dev)
+    fused_row[0, :17] = torch.arange(17, device=dev)
+    fused_cnt = torch.tensor([17], dtype=torch.int32, device=dev)
+    mk = lambda: BatchSearcher(None, None, cross_encoder=ce, chunk_tokens=store, top_k=5, rerank_top_n=t)
+    graphed = mk()
+    monkeypatch.setenv('RAG_GRAPHS', '0')
+    eager = mk()
+    monkeypatch.delenv('RAG_GRAPHS')
+    plen = rag_hip.ce_pair_len_dev(q_off, store.off, 0, torch.zeros(t, dtype=torch.int32, device=dev),
+                                   fused_row.reshape(-1), 512)
+    assert int(plen.sum()) == 2048 and int((plen == 0).sum()) == 3
+    for _ in range(3):                                                   # capture, then replays
+        ia, ca, la = graphed.rerank(q_tok, q_off, fused_row, fused_cnt)
+        ie, ce_, le = eager.rerank(q_tok, q_off, fused_row, fused_cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(ia, ie) and torch.equal(ca, ce_)
+        assert float((la[0, :17] - le[0, :17]).abs().max()) < 2e-6
+    assert any(k[0] == 'rerank' and g is not None for k, g in graphed._graphs.graphs.items())
+    rag_hip.check_faults()
+
+
+def test_the_graph_cache_is_bounded(monkeypatch):
+    """A serving loop with varied shapes must not keep one captured forward (and its memory pool) per shape for ever."""
+    from indexing.bert import GraphCache
+    made = []
+    monkeypatch.setattr('indexing.bert.Graphed', lambda fn, inputs: made.append(1) or (lambda *a: None))
+    c = GraphCache(limit=4)
+    for i in range(10):
+        c.get(('k', i), None, [])
+    assert len(c.graphs) == 4 and ('k', 9) in c.graphs and ('k', 0) not in c.graphs and len(made) == 10
 
 
 def test_class_api_single_calls_replay_graphs(monkeypatch):

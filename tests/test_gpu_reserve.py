@@ -45,6 +45,38 @@ def test_dense_searches_within_a_reservation_do_not_allocate():
     reserved.close()
 
 
+def test_dense_reservation_covers_every_query_block_count_and_the_masked_pre_pass():
+    """A plan's buffer sizes are not monotone in the batch size (strips are rounded per query-block count: three blocks
+    of 256 queries need more workgroups than four), and a row mask switches the pre-pass to its list form: both stay
+    inside a reservation made for the largest batch."""
+    import rag_hip
+    dev = torch.device('cuda:0')
+    rag_hip.init(0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    rows = torch.nn.functional.normalize(torch.randn((400_000, 64), generator=g, device=dev), dim=1)
+    k = 20
+    ix = rag_hip.DenseIndex(rows, metric='cosine', borrow=True)
+    ix.reserve(1024, k)
+    mask = (torch.rand((400_000,), generator=g, device=dev) < 0.7).to(torch.uint8)
+    batches = [129, 257, 513, 600, 700, 768, 769, 900, 1024]
+    qs = {b: torch.nn.functional.normalize(torch.randn((b, 64), generator=g, device=dev), dim=1) for b in batches}
+    outs = {b: (torch.empty((b, k), dtype=torch.float32, device=dev), torch.empty((b, k), dtype=torch.int64, device=dev),
+                torch.empty((b,), dtype=torch.int32, device=dev)) for b in batches}
+    free0 = _free_bytes()
+    for b in batches:
+        ix.search_dev(qs[b], k, out=outs[b])
+        ix.search_dev(qs[b], k, row_mask=mask, out=outs[b])
+    assert _free_bytes() == free0
+    # and the lists are right: the masked search of the last batch against torch
+    s = qs[1024] @ rows.t()
+    s[:, mask == 0] = -2.0
+    want = torch.topk(s, k, dim=1).indices
+    got = outs[1024][1]
+    assert float((torch.sort(got, dim=1).values == torch.sort(want, dim=1).values).float().mean()) > 0.999
+    rag_hip.check_faults()
+    ix.close()
+
+
 def test_bm25_searches_within_a_reservation_do_not_allocate():
     import rag_hip
     from tests import synth

@@ -81,3 +81,77 @@ def test_static_search_refuses_sizes_beyond_its_array():
     want = ix.search_dev(t, o, int(off[-1]), 100)                       # the allocating form takes the same call
     torch.cuda.synchronize()
     assert int(want[2].min()) >= 0
+
+
+def test_static_search_calls_on_two_streams_do_not_race():
+    """All calls on a GPU share that GPU's one work array; calls issued on different streams are chained on the device
+    (each waits for the one before it), so alternating two different batches between two streams, with nothing but the
+    library's own event between them, still gives each batch its own answer."""
+    import torch
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    ix, (term, doc, ln, v) = _index(150_000, 5000, seed=11)
+    batches = [synth.sparse_queries(term, doc, ln, v, 20, seed=31), synth.sparse_queries(term, doc, ln, v, 11, seed=32)]
+    k = 50
+    flat = [rag_hip.Bm25Index.flatten(q) for q in batches]
+    dev_q = [(torch.from_numpy(t).to(dev), torch.from_numpy(o).to(dev), int(o[-1])) for t, o in flat]
+    want = [[x.cpu().numpy() for x in ix.search_dev(t, o, n, k)] for t, o, n in dev_q]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = []
+    for it in range(12):
+        j = it % 2
+        t, o, n = dev_q[j]
+        b = len(batches[j])
+        out = (torch.full((b, k), -7.0, dtype=torch.float64, device=dev), torch.full((b, k), -7, dtype=torch.int64, device=dev),
+               torch.full((b,), -7, dtype=torch.int32, device=dev))
+        with torch.cuda.stream(streams[j]):
+            ix.search_static_dev(t, o, n, k, out)
+        outs.append((j, out))
+    torch.cuda.synchronize()
+    for j, out in outs:
+        _same([x.cpu().numpy() for x in out], want[j])
+
+
+def test_static_search_refuses_on_a_device_without_rag_init():
+    """The entry point allocates nothing, so it cannot set up the device's fault word or look up the array's address
+    itself: without rag_init(device) it returns an error naming the call to make, and works after it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import torch
+import rag_hip
+from tests import synth
+from indexing.bm25_indexer import build_arrays
+torch.zeros(1, device='cuda:0')
+rag_hip._inited_devices.add(0)                 # keep the binding from calling rag_init on first use
+term, doc, ln = synth.sparse_corpus(3000, 300, seed=5, mean_len=20)
+term, _, v = synth.remap_first_appearance(term, 300)
+arr = build_arrays(term, doc, ln, v, 1.5, 0.75)
+ix = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, 3000)
+qs = synth.sparse_queries(term, doc, ln, v, 4, seed=6)
+terms, off = rag_hip.Bm25Index.flatten(qs)
+dev = torch.device('cuda:0')
+t, o = torch.from_numpy(terms).to(dev), torch.from_numpy(off).to(dev)
+mk = lambda: (torch.zeros((4, 10), dtype=torch.float64, device=dev), torch.zeros((4, 10), dtype=torch.int64, device=dev),
+              torch.zeros((4,), dtype=torch.int32, device=dev))
+try:
+    ix.search_static_dev(t, o, int(off[-1]), 10, mk())
+    print('NOT REFUSED')
+except rag_hip.RagHipError as e:
+    print('REFUSED' if 'rag_init' in str(e) else 'OTHER: ' + str(e))
+rag_hip.init(0)
+got = ix.search_static_dev(t, o, int(off[-1]), 10, mk())
+want = ix.search_dev(t, o, int(off[-1]), 10)
+torch.cuda.synchronize()
+print('EQUAL' if all(torch.equal(a, b) for a, b in zip(got, want)) else 'DIFFERENT')
+''' % (root, os.path.join(root, 'domain-rag-system_amd'))
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.split() == ['REFUSED', 'EQUAL'], p.stdout + p.stderr[-2000:]
