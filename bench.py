@@ -57,6 +57,14 @@ def parse():
                     help="cross-encoder arithmetic: 'fp32' = float32 weights and activations, GEMMs and attention as "
                          "split-fp16 matrix-core products with fp32 accumulation (the reference's precision, default); "
                          "'bf16' = the bfloat16 kernels (faster, does not hold the fp32 order); 'fp32-torch' = plain PyTorch ops")
+    ap.add_argument('--ce-screen', default='fp16', choices=['fp16', 'none'],
+                    help="with --ce-dtype fp32: 'fp16' = every pair is first scored by a float16 copy of the cross-encoder (one "
+                         "matrix-core product per product), and only the pairs within a self-checked margin of their query's "
+                         "k-th best go through the float32-equivalent forward, from which the final order and scores come; "
+                         "'none' = every pair through the float32-equivalent forward")
+    ap.add_argument('--screen-safety', type=float, default=1.5,
+                    help='margin of the screen = 2 x this x the largest within-query difference between cheap and exact logits '
+                         'measured on the rescored pairs')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary measurements (rerank_top_n=30, bf16 cross-encoder, batch sweep, host-buffer run) '
                          'and the precision check: for profiler runs')
@@ -351,8 +359,9 @@ def main():
         """The cross-encoder in one of the three arithmetic forms of --ce-dtype."""
         if on_cpu:
             kind = 'fp32-torch'
-        if kind == 'bf16':
-            m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.bfloat16,
+        if kind in ('bf16', 'fp16'):
+            m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev,
+                                      dtype=torch.bfloat16 if kind == 'bf16' else torch.float16,
                                       native=not args.ce_torch_ops)
         elif kind == 'fp32':
             m, _, _ = bert.load_model('random:' + args.ce_arch, 'cross', dev, dtype=torch.float32, native=True,
@@ -365,13 +374,15 @@ def main():
         m.bert.fused_tail = bool(args.ce_fused_attn_out)
         return m
 
-    def make_searcher(model, top_n, with_dist=True):
-        return BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=model,
+    def make_searcher(model, top_n, with_dist=True, screen=None):
+        return BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=model, screen_encoder=screen,
+                             screen_safety=args.screen_safety,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=top_n,
                              ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist if with_dist else None)
 
     ce = load_ce(args.ce_dtype)
-    searcher = make_searcher(ce, args.rerank_top_n)
+    ce_screen = load_ce('fp16') if (args.ce_dtype == 'fp32' and args.ce_screen == 'fp16' and not on_cpu) else None
+    searcher = make_searcher(ce, args.rerank_top_n, screen=ce_screen)
     n_batches = args.steps + args.warmup
     queries = make_queries(args, max(n_batches, 1), dev)
     # work buffers of the two indexes sized once, before anything is timed: no search of the run allocates
@@ -399,6 +410,7 @@ def main():
 
     run(queries[:args.warmup])
     barrier()
+    screen_before = dict(searcher.screen_stats)
     if not on_cpu:
         dense.profile(True)
         rag_hip.enc_mlp_profile(True)
@@ -407,6 +419,7 @@ def main():
     out = run(queries[args.warmup:args.warmup + args.steps])[-1]
     barrier()
     dt = time.perf_counter() - t0
+    screen_after = dict(searcher.screen_stats)
     scan_ms = mlp_ms = lls_ms = np.zeros(0, np.float32)
     mlp_rows = lls_rows = lls_k = np.zeros(0, np.int64)
     if not on_cpu:
@@ -543,8 +556,10 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (kNN) / f64 (BM25, RRF) / %s / %s' % (
-            {'fp32': 'f32 cross-encoder forward with GEMMs and attention as 3 split-fp16 MFMA products (x = hi + lo, 22 significant '
-                     'bits), fp32 accumulation: fp32 round-off class, see precision_check',
+            {'fp32': ('f32 cross-encoder forward with GEMMs and attention as 3 split-fp16 MFMA products (x = hi + lo, 22 significant '
+                      'bits), fp32 accumulation: fp32 round-off class, see precision_check'
+                      + ('; every pair screened first by an f16 forward, order and scores from the f32-equivalent one (rerank_screen)'
+                         if ce_screen is not None else '')),
              'bf16': 'bf16 cross-encoder forward (does NOT hold the fp32 order: see precision_check)',
              'fp32-torch': 'f32 cross-encoder forward (PyTorch ops)'}[args.ce_dtype],
             'f32 (embedder forward)' if args.embed_fp32_gemm or args.embed_torch_ops else
@@ -560,10 +575,22 @@ def main():
                    'parallelism': 'rows sharded x%d, all-gather top-k, pairs split' % world if world > 1 else 'single GPU',
                    'batch_pipelining': bool(world == 1 and args.pipeline and args.steps > 1)},
         'stage_ms_per_step': stage_ms,
+        'rerank_screen': None,
         # `roofline`: the hand-written kernel with the largest share of a step (the feed-forward block); the dense scan beside it
         'roofline': roofline_ff if roofline_ff is not None else roofline,
         'roofline_dense_scan': roofline,
     }
+    if searcher.screen_encoder is not None and screen_after['pairs'] > screen_before['pairs']:
+        n_p = screen_after['pairs'] - screen_before['pairs']
+        result['rerank_screen'] = {
+            'screen': 'float16 copy of the cross-encoder on every pair (one MFMA product per product); pairs within the margin '
+                      "of their query's k-th best cheap logit are rescored by the float32-equivalent forward; order and "
+                      'rerank_score come from the rescored logits only',
+            'rescored_fraction': round((screen_after['rescored'] - screen_before['rescored']) / n_p, 4),
+            'pairs_per_step': n_p // max(args.steps, 1), 'safety': args.screen_safety,
+            'within_query_error_max': searcher.screen_stats['err_max'],
+            'margin': 2.0 * args.screen_safety * float(searcher._screen_err or 0.0),
+            'margin_widened_in_timed_steps': screen_after['widened'] - screen_before['widened']}
     off_h = tok_h = None
 
     def search_with(srch, q):
@@ -591,6 +618,7 @@ def main():
         # two different summation orders cannot be told apart there).
         eps = 2e-5
         o_timed = search_with(searcher, queries[0])
+        exact_mask = searcher.last_rescored               # None: every logit is an exact one
         ce_ref = load_ce('fp32-torch')
         o_ref = search_with(make_searcher(ce_ref, t), queries[0])
         k = args.top_k
@@ -598,22 +626,36 @@ def main():
         gap = (ref_sorted[:, :k] - ref_sorted[:, 1:k + 1]).min(dim=1).values
         same = (o_timed['rows'] == o_ref['rows']).all(dim=1)
         fused_same = bool((o_timed['fused_row'] == o_ref['fused_row']).all())
-        err = float((o_timed['logits'].double() - o_ref['logits'].double()).abs().max())
+        diff = (o_timed['logits'].double() - o_ref['logits'].double()).abs()
+        err = float(diff.max() if exact_mask is None else diff[exact_mask].max())
+        score_err = float((o_timed['rerank_score'].double() - o_ref['rerank_score'].double())[same].abs().max())
         result['precision_check'] = {
             'reference': 'plain PyTorch float32 cross-encoder forward on the same fused candidates',
             'queries': int(same.numel()), 'top_k_ids_identical': int(same.sum()),
             'differing_with_fp32_gap_below_eps': int((~same & (gap < eps)).sum()),
             'differing_unexcused': int((~same & (gap >= eps)).sum()), 'eps': eps,
             'fused_candidates_identical': fused_same, 'max_abs_logit_error': err,
+            'max_abs_rerank_score_error': score_err,
+            'logits_compared': int(diff.numel() if exact_mask is None else exact_mask.sum()),
+            'rescored_fraction_of_this_batch': None if exact_mask is None else round(float(exact_mask.float().mean()), 4),
             'median_deciding_gap_fp32': float(gap.median())}
         del ce_ref
 
         # (2) secondary measurements, each a few timed steps of the same batches
         nx = max(1, min(args.extra_steps, len(queries)))
         extra = {}
-        v, ms = time_steps(make_searcher(ce, 30), queries[:nx])
+        s30 = make_searcher(ce, 30, screen=ce_screen)
+        v, ms = time_steps(s30, queries[:nx])
         extra['rerank_top_n_30'] = {'value': v, 'ms_per_step': ms, 'unit': 'queries/sec',
                                     'note': 'same path with --rerank_top_n 30 (60 entries per list, 30 pairs per query)'}
+        if ce_screen is not None:
+            st = s30.screen_stats
+            # (the first batch of a fresh searcher rescores every pair: the fraction of the batches after it)
+            extra['rerank_top_n_30']['rescored_fraction_all_batches'] = round(st['rescored'] / max(st['pairs'], 1), 4)
+            v, ms = time_steps(make_searcher(ce, t), queries[:nx])
+            extra['without_screen'] = {'value': v, 'ms_per_step': ms, 'unit': 'queries/sec',
+                                       'note': 'every pair through the float32-equivalent forward (--ce-screen none)'}
+        del s30
         # the pipeline every timing the reference publishes was taken on (evaluation/comprehensive_evaluation.py:233-241:
         # hybrid RRF, reranker_kind='simple', rerank_top_n=50, top_k=10; 1.37-1.85 s per query on 91,853 chunks there):
         # the simple reranker's cosines come from the resident rows (rag_dense_rescore_dev)
@@ -637,6 +679,16 @@ def main():
             'top_k_ids_identical_to_fp32': '%d/%d' % (int(same_o.sum()), int(same_o.numel())),
             'max_abs_logit_error': float((o_other['logits'].double() - o_ref['logits'].double()).abs().max())}
         del ce_other, s_other
+        if ce_screen is not None:              # the screening forward on its own: its speed and how often it alone would do
+            s_h = make_searcher(ce_screen, t)
+            v, ms = time_steps(s_h, queries[:nx])
+            o_h = search_with(s_h, queries[0])
+            same_h = (o_h['rows'] == o_ref['rows']).all(dim=1)
+            extra['cross_encoder_fp16_alone'] = {
+                'value': v, 'ms_per_step': ms, 'unit': 'queries/sec',
+                'top_k_ids_identical_to_fp32': '%d/%d' % (int(same_h.sum()), int(same_h.numel())),
+                'max_abs_logit_error': float((o_h['logits'].double() - o_ref['logits'].double()).abs().max())}
+            del s_h
         sweep = []
         for bsz in (1, 32, 256):
             sub = argparse.Namespace(**{**vars(args), 'batch': bsz})

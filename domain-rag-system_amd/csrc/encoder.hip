@@ -6,8 +6,8 @@
 //  attention_kernel   softmax(Q K^T / sqrt(D) + key mask) V for one (sequence, head) per
 //                     workgroup, straight from the packed [tokens][3][heads][D] projection
 //                     output to the [tokens][heads*D] layout the output projection reads
-//                     (no transposes, no score matrix in memory).  bf16 in/out, fp32 softmax,
-//                     v_mfma_f32_32x32x16_bf16 for both products.
+//                     (no transposes, no score matrix in memory).  bf16 or fp16 in/out, fp32 softmax,
+//                     v_mfma_f32_32x32x16_bf16 / _f16 for both products.
 //  add_layernorm_kernel   LayerNorm(x + residual) in one pass, fp32 arithmetic, one wave per row.
 #include "common.h"
 
@@ -77,6 +77,20 @@ template <> struct Vec8<bf16> {
         *reinterpret_cast<bf16x8*>(p) = v;
     }
 };
+template <> struct Vec8<f16> {
+    typedef Half16<f16>::x8 type;
+    __device__ static void load(const f16* p, float* f) {
+        const type v = *reinterpret_cast<const type*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    __device__ static void store(f16* p, const float* f) {
+        type v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)f[j];
+        *reinterpret_cast<type*>(p) = v;
+    }
+};
 template <> struct Vec8<float> {
     __device__ static void load(const float* p, float* f) {
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -96,15 +110,18 @@ constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes 
 #ifndef RAG_ATT_MIN_BLOCKS
 #define RAG_ATT_MIN_BLOCKS 6         // workgroups per CU the register budget is sized for
 #endif
-template <int D>
-__global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(const bf16* __restrict__ qkv,
+template <int D, typename E>
+__global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(const E* __restrict__ qkv,
                                                            const int32_t* __restrict__ lens,
                                                            const int32_t* __restrict__ cu, int64_t total_tokens,
                                                            int n_seq, int S_max, int NH, float scale,
-                                                           int first_only, bf16* __restrict__ out, uint32_t* fault) {
+                                                           int first_only, E* __restrict__ out, uint32_t* fault) {
     // first_only: only the first token of every sequence is a query ([CLS] of the last layer, the
     // one row the pooler reads); out is then [n_seq][H]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Half16<E>::x8 e8;
+    typedef typename Half16<E>::x4 e4;
+    typedef typename Half16<E>::x2 e2;
     constexpr int KROW = D + 8;
     constexpr int DT = D / 32;                    // 32-row tiles of the transposed output
     constexpr int KC = D / 16;                    // k-steps of the score product
@@ -138,49 +155,48 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
         S = S_max;
         len = min(max(lens[seq], 0), S);
     }
-    const bf16* base = qkv + (size_t)first * tok;
-    bf16* obase = first_only ? out + (size_t)seq * H + head * D : out + (size_t)first * H + head * D;
+    const E* base = qkv + (size_t)first * tok;
+    E* obase = first_only ? out + (size_t)seq * H + head * D : out + (size_t)first * H + head * D;
     const int kpad = (len + 31) & ~31;
     const int VROW = kpad + 4;
-    bf16* Ks = reinterpret_cast<bf16*>(smem);
-    bf16* Vt = Ks + (size_t)kpad * KROW;
+    E* Ks = reinterpret_cast<E*>(smem);
+    E* Vt = Ks + (size_t)kpad * KROW;
 
     // ---- stage this head's keys (row-major) and values (transposed), zero beyond len
     // Q^T fragments (B operand) of this wave's first query block: lane (h, r) holds Q[q][16c + 8h + j].
     // Issued before the K/V staging so that both round trips to memory overlap.
     const int n_query_rows = first_only ? 1 : S;
-    bf16x8 qf[KC];
+    e8 qf[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
+        for (int j = 0; j < 8; ++j) qf[c][j] = (E)0.f;
         if (wave * 32 + r < S && wave * 32 < min(n_query_rows, len))
-            qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)(wave * 32 + r) * tok + head * D + 16 * c + 8 * h);
+            qf[c] = *reinterpret_cast<const e8*>(base + (size_t)(wave * 32 + r) * tok + head * D + 16 * c + 8 * h);
     }
     // each thread moves 8 dims of two neighbouring keys, so the transposed image is written 4 bytes at a time
-    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
     for (int idx = tid; idx < (kpad / 2) * (D / 8); idx += (int)blockDim.x) {
         const int key = (idx / (D / 8)) * 2, c8 = idx % (D / 8);
-        bf16x8 k0, k1, v0, v1;
+        e8 k0, k1, v0, v1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { k0[j] = (bf16)0.f; k1[j] = (bf16)0.f; v0[j] = (bf16)0.f; v1[j] = (bf16)0.f; }
-        const bf16* p = base + (size_t)key * tok + head * D + c8 * 8;
+        for (int j = 0; j < 8; ++j) { k0[j] = (E)0.f; k1[j] = (E)0.f; v0[j] = (E)0.f; v1[j] = (E)0.f; }
+        const E* p = base + (size_t)key * tok + head * D + c8 * 8;
         if (key < len) {
-            k0 = *reinterpret_cast<const bf16x8*>(p + H);
-            v0 = *reinterpret_cast<const bf16x8*>(p + 2 * H);
+            k0 = *reinterpret_cast<const e8*>(p + H);
+            v0 = *reinterpret_cast<const e8*>(p + 2 * H);
         }
         if (key + 1 < len) {
-            k1 = *reinterpret_cast<const bf16x8*>(p + tok + H);
-            v1 = *reinterpret_cast<const bf16x8*>(p + tok + 2 * H);
+            k1 = *reinterpret_cast<const e8*>(p + tok + H);
+            v1 = *reinterpret_cast<const e8*>(p + tok + 2 * H);
         }
-        *reinterpret_cast<bf16x8*>(Ks + key * KROW + c8 * 8) = k0;
-        *reinterpret_cast<bf16x8*>(Ks + (key + 1) * KROW + c8 * 8) = k1;
+        *reinterpret_cast<e8*>(Ks + key * KROW + c8 * 8) = k0;
+        *reinterpret_cast<e8*>(Ks + (key + 1) * KROW + c8 * 8) = k1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            bf16x2 pr;
+            e2 pr;
             pr[0] = v0[j];
             pr[1] = v1[j];
-            *reinterpret_cast<bf16x2*>(Vt + (c8 * 8 + j) * VROW + key) = pr;
+            *reinterpret_cast<e2*>(Vt + (c8 * 8 + j) * VROW + key) = pr;
         }
     }
     __syncthreads();
@@ -192,10 +208,10 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
             for (int i = lane; i < 32 * (D / 8); i += 64) {
                 const int row = qb * 32 + i / (D / 8), c8 = i % (D / 8);
                 if (row < n_query_rows) {
-                    bf16x8 z;
+                    e8 z;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
-                    *reinterpret_cast<bf16x8*>(obase + (size_t)row * H + c8 * 8) = z;
+                    for (int j = 0; j < 8; ++j) z[j] = (E)0.f;
+                    *reinterpret_cast<e8*>(obase + (size_t)row * H + c8 * 8) = z;
                 }
             }
             continue;
@@ -204,8 +220,8 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) qf[c][j] = (bf16)0.f;
-                if (q < S) qf[c] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * tok + head * D + 16 * c + 8 * h);
+                for (int j = 0; j < 8; ++j) qf[c][j] = (E)0.f;
+                if (q < S) qf[c] = *reinterpret_cast<const e8*>(base + (size_t)q * tok + head * D + 16 * c + 8 * h);
             }
         }
         float m_run = NEG_BIG, l_run = 0.f;
@@ -222,8 +238,8 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + (kb + r) * KROW + 16 * c + 8 * h);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[c], s, 0, 0, 0);
+                const e8 a = *reinterpret_cast<const e8*>(Ks + (kb + r) * KROW + 16 * c + 8 * h);
+                s = Half16<E>::mfma(a, qf[c], s);
             }
             // softmax in base 2: t = s * (scale * log2 e), p = 2^(t - m); only the last key block
             // can hold keys beyond len
@@ -266,18 +282,18 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
             // lane half h is key kb + 16t + 8(j>>2) + 4h + (j&3), so V^T is read in that order
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                bf16x8 pb;
+                e8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (bf16)s[8 * t + j];
+                for (int j = 0; j < 8; ++j) pb[j] = (E)s[8 * t + j];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16* vp = Vt + (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vp + 8);
-                    bf16x8 av;
+                    const E* vp = Vt + (size_t)(dt * 32 + r) * VROW + kb + 16 * t + 4 * h;
+                    const e4 lo = *reinterpret_cast<const e4*>(vp);
+                    const e4 hi = *reinterpret_cast<const e4*>(vp + 8);
+                    e8 av;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { av[j] = lo[j]; av[4 + j] = hi[j]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, o[dt], 0, 0, 0);
+                    o[dt] = Half16<E>::mfma(av, pb, o[dt]);
                 }
             }
         }
@@ -292,9 +308,9 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
             uint2 grp[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
+                e4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[dt][4 * g + j] * inv);
+                for (int j = 0; j < 4; ++j) v[j] = (E)(o[dt][4 * g + j] * inv);
                 grp[g] = __builtin_bit_cast(uint2, v);
             }
             // lower lane sends groups 1, 3 and keeps 0, 2; upper lane sends 0, 2 and keeps 1, 3
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
             const uint2 a0 = h ? got0 : grp[0], a1 = h ? grp[1] : got0;
             const uint2 b0 = h ? got1 : grp[2], b1 = h ? grp[3] : got1;
             if (q < n_query_rows) {
-                bf16* dst = obase + (size_t)q * H + dt * 32 + 8 * h;
+                E* dst = obase + (size_t)q * H + dt * 32 + 8 * h;
                 *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, a1.x, a1.y);
                 *reinterpret_cast<uint4*>(dst + 16) = make_uint4(b0.x, b0.y, b1.x, b1.y);
             }
@@ -1057,9 +1073,10 @@ namespace {
 int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_cu, int64_t total_tokens, int32_t n_seq,
                      int32_t seq_len, int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_,
                      int first_only) {
-    RAG_REQUIRE(!first_only || dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attention: first-token form is bf16 only");
+    RAG_REQUIRE(!first_only || dtype != RAG_DTYPE_F32, RAG_ELIMIT, "rag_enc_attention: first-token form is bf16 / fp16 only");
     RAG_REQUIRE(n_seq >= 0 && seq_len >= 1 && n_heads >= 1, RAG_EINVAL, "rag_enc_attention: bad sizes");
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_attention: unknown dtype");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16 || dtype == RAG_DTYPE_F32, RAG_EINVAL,
+                "rag_enc_attention: unknown dtype");
     RAG_REQUIRE(head_dim == 32 || head_dim == 64, RAG_ELIMIT, "rag_enc_attention: head_dim must be 32 or 64 (got %d)",
                 head_dim);
     RAG_REQUIRE(seq_len <= RAG_ENC_MAX_SEQ, RAG_ELIMIT, "rag_enc_attention: seq_len %d exceeds %d", seq_len,
@@ -1088,15 +1105,18 @@ int attention_launch(const void* d_qkv, const int32_t* d_lens, const int32_t* d_
         RAG_HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    if (head_dim == 32) {
-        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_kernel<32>, 160 * 1024);
-        attention_kernel<32><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
-                                                            n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
-    } else {
-        if (lds > 64 * 1024) RAG_GRANT_LDS(attention_kernel<64>, 160 * 1024);
-        attention_kernel<64><<<grid, att_nt, lds, stream>>>((const bf16*)d_qkv, d_lens, d_cu, total_tokens, n_seq, seq_len,
-                                                            n_heads, scale, first_only, (bf16*)d_out, rag_fault_word());
-    }
+#define RAG_ATT_LAUNCH(D_, E_)                                                                                          \
+    do {                                                                                                                \
+        if (lds > 64 * 1024) RAG_GRANT_LDS((attention_kernel<D_, E_>), 160 * 1024);                                     \
+        attention_kernel<D_, E_><<<grid, att_nt, lds, stream>>>((const E_*)d_qkv, d_lens, d_cu, total_tokens, n_seq,    \
+                                                                seq_len, n_heads, scale, first_only, (E_*)d_out,        \
+                                                                rag_fault_word());                                      \
+    } while (0)
+    if (head_dim == 32 && dtype == RAG_DTYPE_BF16) RAG_ATT_LAUNCH(32, bf16);
+    else if (head_dim == 32) RAG_ATT_LAUNCH(32, f16);
+    else if (dtype == RAG_DTYPE_BF16) RAG_ATT_LAUNCH(64, bf16);
+    else RAG_ATT_LAUNCH(64, f16);
+#undef RAG_ATT_LAUNCH
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -1107,7 +1127,8 @@ extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual
                                          void* d_out, void* stream_) {
     RAG_REQUIRE(rows >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
                 "rag_enc_add_layernorm: hidden must be a multiple of 8 up to %d (got %d)", 8 * 64 * LN_MAX_CHUNKS, hidden);
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_add_layernorm: unknown dtype");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16 || dtype == RAG_DTYPE_F32, RAG_EINVAL,
+                "rag_enc_add_layernorm: unknown dtype");
     if (rows == 0) return RAG_OK;
     RAG_REQUIRE(d_x && d_gamma && d_beta && d_out, RAG_EINVAL, "rag_enc_add_layernorm: null pointer");
     RAG_REQUIRE((rows + 3) / 4 < (1ll << 31), RAG_ELIMIT, "rag_enc_add_layernorm: too many rows");
@@ -1117,6 +1138,9 @@ extern "C" int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual
         add_layernorm_kernel<bf16><<<grid, 256, 0, stream>>>((const bf16*)d_x, (const bf16*)d_residual,
                                                              (const bf16*)d_gamma, (const bf16*)d_beta, eps, rows, hidden,
                                                              (bf16*)d_out);
+    else if (dtype == RAG_DTYPE_F16)
+        add_layernorm_kernel<f16><<<grid, 256, 0, stream>>>((const f16*)d_x, (const f16*)d_residual, (const f16*)d_gamma,
+                                                            (const f16*)d_beta, eps, rows, hidden, (f16*)d_out);
     else
         add_layernorm_kernel<float><<<grid, 256, 0, stream>>>((const float*)d_x, (const float*)d_residual,
                                                               (const float*)d_gamma, (const float*)d_beta, eps, rows,
@@ -1133,7 +1157,8 @@ int embed_layernorm_launch(const int32_t* d_ids, const int32_t* d_types, const i
     RAG_REQUIRE(n_tokens >= 0 && hidden >= 8 && hidden % 8 == 0 && hidden <= 8 * 64 * LN_MAX_CHUNKS, RAG_ELIMIT,
                 "rag_enc_embed_layernorm: hidden must be a multiple of 8 up to %d (got %d)", 8 * 64 * LN_MAX_CHUNKS, hidden);
     RAG_REQUIRE(vocab >= 1 && max_pos >= 1 && n_types >= 1, RAG_EINVAL, "rag_enc_embed_layernorm: empty table");
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F32, RAG_EINVAL, "rag_enc_embed_layernorm: unknown dtype");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16 || dtype == RAG_DTYPE_F32, RAG_EINVAL,
+                "rag_enc_embed_layernorm: unknown dtype");
     RAG_REQUIRE(d_out_split == nullptr || (dtype == RAG_DTYPE_F32 && (half_dtype == RAG_DTYPE_BF16 || half_dtype == RAG_DTYPE_F16)),
                 RAG_EINVAL, "rag_enc_embed_layernorm_split: fp32 tables and bf16 or fp16 halves");
     if (n_tokens == 0) return RAG_OK;
@@ -1148,6 +1173,12 @@ int embed_layernorm_launch(const int32_t* d_ids, const int32_t* d_types, const i
                                                                (const bf16*)d_gamma, (const bf16*)d_beta, eps, n_tokens,
                                                                hidden, vocab, max_pos, n_types, (bf16*)d_out,
                                                                rag_fault_word());
+    else if (dtype == RAG_DTYPE_F16)
+        embed_layernorm_kernel<f16><<<grid, 256, 0, stream>>>(d_ids, d_types, d_pos, (const f16*)d_word,
+                                                              (const f16*)d_position, (const f16*)d_type_emb,
+                                                              (const f16*)d_gamma, (const f16*)d_beta, eps, n_tokens,
+                                                              hidden, vocab, max_pos, n_types, (f16*)d_out,
+                                                              rag_fault_word());
     else if (d_out_split != nullptr && half_dtype == RAG_DTYPE_F16)
         embed_layernorm_kernel<float, _Float16><<<grid, 256, 0, stream>>>(
             d_ids, d_types, d_pos, (const float*)d_word, (const float*)d_position, (const float*)d_type_emb,

@@ -2,8 +2,8 @@
 //
 //   Y = LayerNorm( X + GELU(X W1^T + b1) W2^T + b2 ) * gamma + beta
 //
-// X, Y [M][384] bf16; W1 [I][384], W2 [384][I] (nn.Linear layouts), fp32 accumulation on
-// v_mfma_f32_32x32x16_bf16.  The [M][I] intermediate (I = 1536: four times the layer's input) never
+// X, Y [M][384] bf16 or fp16 (template parameter E); W1 [I][384], W2 [384][I] (nn.Linear layouts), fp32
+// accumulation on v_mfma_f32_32x32x16_bf16 / _f16.  The [M][I] intermediate (I = 1536: four times the layer's input) never
 // leaves the chip: per token the block reads 768 B and writes 768 B, where two GEMMs, a GELU pass
 // and a residual+LayerNorm pass move 11.5 KB.  gfx950 only.
 //
@@ -25,7 +25,7 @@
 // W2 rows are staged in the same swapped order, so Y^T comes out in the layout of the X fragments:
 // the epilogue adds bias and the residual (the block's own input, still in registers), takes the
 // LayerNorm statistics of a token from the lane and its partner in the other half-wave, and
-// stores bf16 in 16-byte pieces.
+// stores 16-bit values in 16-byte pieces.
 //
 // Behind CrossEncoderReranker.score_pairs (reference src/reranker/rerank.py:79-84): the
 // intermediate / output sub-layers of the BertForSequenceClassification forward that
@@ -53,6 +53,18 @@ typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16;
+// the 16-bit element type of a kernel instance: bfloat16 (range of fp32, 8 significant bits) or float16 (11 bits,
+// values below 65504), the same matrix-core rate either way
+template <typename E> struct El16;
+template <> struct El16<bf16> {
+    typedef bf16 x8 __attribute__((ext_vector_type(8)));
+    __device__ static __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct El16<f16> {
+    typedef f16 x8 __attribute__((ext_vector_type(8)));
+    __device__ static __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -72,24 +84,25 @@ constexpr int ML_MAX_I = 8192;               // b1 sits in LDS
 constexpr int ML_OFF_W2 = 2 * ML_W_BYTES;
 constexpr int ML_OFF_B1 = 4 * ML_W_BYTES;
 
-struct MlpParams {
-    const bf16* x;        // [M][384]
-    const bf16* w1;       // [I][384]
-    const bf16* b1;       // [I]
-    const bf16* w2;       // [384][I]
-    const bf16* b2;       // [384]
-    const bf16* gamma;    // [384]
-    const bf16* beta;     // [384]
-    bf16* y;              // [M][384]
+template <typename E>
+struct MlpParamsT {
+    const E* x;        // [M][384]
+    const E* w1;       // [I][384]
+    const E* b1;       // [I]
+    const E* w2;       // [384][I]
+    const E* b2;       // [384]
+    const E* gamma;    // [384]
+    const E* beta;     // [384]
+    E* y;              // [M][384]
     int64_t M;
     int I;
     float eps;
     // attention-output projection in front of the block (PROJ kernels): x above is then the layer's input
-    const bf16* ctx;      // [M][384] attention output
-    const bf16* wo;       // [384][384]
-    const bf16* bo;       // [384]
-    const bf16* gamma1;   // [384]
-    const bf16* beta1;    // [384]
+    const E* ctx;      // [M][384] attention output
+    const E* wo;       // [384][384]
+    const E* bo;       // [384]
+    const E* gamma1;   // [384]
+    const E* beta1;    // [384]
 };
 
 // One wave-instruction of a direct-to-LDS load: lane l's 16 bytes at gbase + voff land at LDS byte
@@ -127,7 +140,8 @@ __device__ __forceinline__ void unrolled(std::integer_sequence<int, Is...>, F&& 
 
 // GELU(v) = v Phi(v), Phi(v) = (1 + erf(v / sqrt 2)) / 2, for two values at a time.  Phi(v) - 1/2 is an
 // odd degree-17 polynomial in v fitted on |v| <= 4.525 and held constant beyond (Phi(4.525) = 1 - 3e-6):
-// absolute error of the GELU below 6e-5, a fiftieth of the bf16 rounding of values near 1 — and no
+// absolute error of the GELU below 6e-5, a fiftieth of the bf16 rounding of values near 1 (an eighth of the
+// fp16 one) — and no
 // exponential or reciprocal, which run at a quarter of the FMA rate.
 // The same evaluation in three slices (head: clamp, square, three FMAs; mid: four FMAs; tail: the rest).
 #define ML_K2(x) ((f32x2){x, x})
@@ -160,8 +174,9 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
 // MODE 0: the feed-forward block of x.  MODE 1 (PROJ): x1 = LN1(x + ctx Wo^T + bo) first, then the block of x1.
 // MODE 2: x1 = LN1(x + ctx) first, ctx being the finished attention-output projection (bias included): the
 // residual + LayerNorm pass between the projection and this kernel, done on the rows this kernel loads anyway.
-template <int MODE>
-__global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
+template <typename E, int MODE>
+__global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
+    typedef typename El16<E>::x8 e8;
     constexpr bool PROJ = MODE == 1;
     constexpr bool PRE_LN = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -198,12 +213,12 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         offo[i] = (uint32_t)((fo * ML_HID + j2 * 8) * 2);
     }
     auto dma_w1 = [&](int c, int buf) {                      // chunk c of W1 -> W1 buffer buf
-        const bf16* g = p.w1 + (size_t)c * ML_C * ML_HID;
+        const E* g = p.w1 + (size_t)c * ML_C * ML_HID;
 #pragma unroll
         for (int i = 0; i < ML_W_DMAS; ++i) lds_dma16(lds0 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), g, off1[i]);
     };
     auto dma_w2 = [&](int c, int buf) {
-        const bf16* g = p.w2 + c * ML_C;
+        const E* g = p.w2 + c * ML_C;
 #pragma unroll
         for (int i = 0; i < ML_W_DMAS; ++i)
             lds_dma16(lds0 + ML_OFF_W2 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), g, off2[i]);
@@ -213,20 +228,20 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     dma_w1(min(1, last), 1);
     if constexpr (!PROJ) dma_w2(0, 0);   // PROJ: the W2 buffers carry Wo first
     for (int i = tid; i < p.I; i += ML_NT) *reinterpret_cast<float*>(smem + ML_OFF_B1 + 4 * i) = (float)p.b1[i];
-    for (int i = tid; i < (PRE_LN ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, bf16
+    for (int i = tid; i < (PRE_LN ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, 16-bit
         const int vsel = i / (ML_HID / 8), piece = i % (ML_HID / 8);
-        const bf16* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : vsel == 2 ? p.beta : vsel == 3 ? (PROJ ? p.bo : p.b2) : vsel == 4 ? p.gamma1 : p.beta1;
-        *reinterpret_cast<bf16x8*>(smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (vsel * ML_HID + piece * 8)) =
-            *reinterpret_cast<const bf16x8*>(src + piece * 8);
+        const E* src = vsel == 0 ? p.b2 : vsel == 1 ? p.gamma : vsel == 2 ? p.beta : vsel == 3 ? (PROJ ? p.bo : p.b2) : vsel == 4 ? p.gamma1 : p.beta1;
+        *reinterpret_cast<e8*>(smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (vsel * ML_HID + piece * 8)) =
+            *reinterpret_cast<const e8*>(src + piece * 8);
     }
 
     // ---- the wave's 32 rows of X as B fragments: lane (r, h) holds X[tok][16t + 8h .. + 7]
     // (PROJ: the rows of the attention output first; X is then computed below)
-    bf16x8 xf[ML_KS];
+    e8 xf[ML_KS];
     {
-        const bf16* xrow = (PRE_LN ? p.ctx : p.x) + tok_ld * ML_HID + 8 * h;
+        const E* xrow = (PRE_LN ? p.ctx : p.x) + tok_ld * ML_HID + 8 * h;
 #pragma unroll
-        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
+        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
     }
 
     // ---- fragment addresses.  First product, k-step t: piece 2t + h of image row r, at
@@ -251,17 +266,17 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(a1[t & 7] + buf * ML_W_BYTES + 256 * (t >> 3));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[t], acc, 0, 0, 0);
+            const e8 a = *reinterpret_cast<const e8*>(a1[t & 7] + buf * ML_W_BYTES + 256 * (t >> 3));
+            acc = El16<E>::mfma(a, xf[t], acc);
         }
     };
-    auto gelu_pack = [&](int c, const f32x16& acc, bf16x8* pf) {
+    auto gelu_pack = [&](int c, const f32x16& acc, e8* pf) {
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const f32x2 b = *reinterpret_cast<const f32x2*>(b1s + c * (ML_C * 4) + 64 * (i >> 3) + 4 * (i & 7));
             const f32x2 g = gelu2((f32x2){acc[i], acc[i + 1]} + b);
-            pf[i >> 3][i & 7] = (bf16)g.x;
-            pf[i >> 3][(i & 7) + 1] = (bf16)g.y;
+            pf[i >> 3][i & 7] = (E)g.x;
+            pf[i >> 3][(i & 7) + 1] = (E)g.y;
         }
     };
 
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         // the two W2 buffers in 12 slices of 32 input columns (the W2 image shape: 24 MFMAs per slice,
         // fragment reads issued ML_PO MFMAs ahead).  With the Wo rows in the swapped order, registers
         // 8t..8t+7 of tile m are features 32m + 16t + 8h + 0..7 of the lane's token: after the LayerNorm
-        // they are, converted to bf16, exactly the fragment xf[2m + t].
+        // they are, converted to the 16-bit element type, exactly the fragment xf[2m + t].
         constexpr int ML_PO = 6;
         auto dma_wo = [&](int kc, int buf, int i) {
             lds_dma16(lds0 + ML_OFF_W2 + buf * ML_W_BYTES + 1024 * (wave + 4 * i), p.wo + kc * ML_C, offo[i]);
@@ -301,8 +316,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
                 constexpr int newer = ML_KS - 1 - S < ML_PO ? ML_KS - 1 - S : ML_PO;
                 lds_wait<newer>(q[S % (ML_PO + 1)]);
                 constexpr int M = S % ML_YT, T = S / ML_YT;
-                yacc[M] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q[S % (ML_PO + 1)]),
-                                                                  xf[2 * KC + T], yacc[M], 0, 0, 0);
+                yacc[M] = El16<E>::mfma(__builtin_bit_cast(e8, q[S % (ML_PO + 1)]),
+                                                                  xf[2 * KC + T], yacc[M]);
             };
             unrolled(std::make_integer_sequence<int, ML_PO>{}, issue);
             unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
@@ -316,12 +331,12 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         // (MODE 2: the accumulator registers only serve as the fp32 copy of the row)
         if constexpr (!PROJ) __syncthreads();                 // gamma1 | beta1 were staged by other threads
         const unsigned char* v1 = smem + ML_OFF_B1 + 4 * (size_t)p.I + 2 * (3 * ML_HID) + 16 * h;   // bo | gamma1 | beta1
-        const bf16* xin = p.x + tok_ld * ML_HID + 8 * h;
+        const E* xin = p.x + tok_ld * ML_HID + 8 * h;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) {
-            const bf16x8 xr = *reinterpret_cast<const bf16x8*>(xin + 16 * t);
-            const bf16x8 bb = *reinterpret_cast<const bf16x8*>(v1 + 32 * t);
+            const e8 xr = *reinterpret_cast<const e8*>(xin + 16 * t);
+            const e8 bb = *reinterpret_cast<const e8*>(v1 + 32 * t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = PROJ ? yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xr[j]
@@ -341,11 +356,11 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
         const float rstd = rsqrtf(sq / (float)ML_HID + p.eps);
 #pragma unroll
         for (int t = 0; t < ML_KS; ++t) {
-            const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(v1 + 2 * ML_HID + 32 * t);
-            const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(v1 + 4 * ML_HID + 32 * t);
+            const e8 g8 = *reinterpret_cast<const e8*>(v1 + 2 * ML_HID + 32 * t);
+            const e8 be8 = *reinterpret_cast<const e8*>(v1 + 4 * ML_HID + 32 * t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                xf[t][j] = (bf16)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+                xf[t][j] = (E)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
                 yacc[t >> 1][8 * (t & 1) + j] = 0.f;
             }
         }
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 
     // ---- prologue: H^T of chunks 0 and 1; then W1 buffer 0 is free for chunk 2
     f32x16 hA, hB;
-    bf16x8 pA[2], pB[2];
+    e8 pA[2], pB[2];
     gemm1(0, hA);
     gemm1(1, hB);
     __syncthreads();
@@ -375,14 +390,14 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 #if ML_STAMPS
     unsigned long long st[5] = {0, 0, 0, 0, 0};
 #endif
-    auto iteration = [&](int c, auto buf_c, f32x16& hnew, const f32x16& hold, const bf16x8* pcur, bf16x8* pnext) {
+    auto iteration = [&](int c, auto buf_c, f32x16& hnew, const f32x16& hold, const e8* pcur, e8* pnext) {
         constexpr int BUF = decltype(buf_c)::value;
         ML_STAMP(t0);
         // the weight loads are issued one per k-step over the first half of the steps, between MFMAs
         // (issuing one costs the wave some 50 cycles, which the matrix unit covers there and would not
         // cover in one block up front; the second half of the steps gives the last ones time to land)
-        const bf16* g1 = p.w1 + (size_t)min(c + 3, last) * ML_C * ML_HID;
-        const bf16* g2 = p.w2 + min(c + 1, last) * ML_C;
+        const E* g1 = p.w1 + (size_t)min(c + 3, last) * ML_C * ML_HID;
+        const E* g2 = p.w2 + min(c + 1, last) * ML_C;
         ML_STAMP(t1);
         // bias of chunk c+1 (for the GELU), then the fragment ring: k-step s uses slot s % (ML_PF + 1)
         f32x4 bias[4];
@@ -412,11 +427,11 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
             constexpr int newer = 2 * (ML_KS - 1 - S < ML_PF ? ML_KS - 1 - S : ML_PF);   // reads issued after this step's
             lds_wait<newer>(q1[S % (ML_PF + 1)], q2[S % (ML_PF + 1)]);
             if constexpr (S == 0)
-                hnew = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q1[0]), xf[0], zero16, 0, 0, 0);
+                hnew = El16<E>::mfma(__builtin_bit_cast(e8, q1[0]), xf[0], zero16);
             else
-                hnew = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q1[S % (ML_PF + 1)]), xf[S], hnew, 0, 0, 0);
+                hnew = El16<E>::mfma(__builtin_bit_cast(e8, q1[S % (ML_PF + 1)]), xf[S], hnew);
             constexpr int M = S % ML_YT, T = S / ML_YT;
-            yacc[M] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q2[S % (ML_PF + 1)]), pcur[T], yacc[M], 0, 0, 0);
+            yacc[M] = El16<E>::mfma(__builtin_bit_cast(e8, q2[S % (ML_PF + 1)]), pcur[T], yacc[M]);
             // the GELU of one register pair is spread over three k-steps, each slice pinned behind this
             // step's MFMAs (the empty asm statements keep their place among the LDS statements), so the
             // vector work issues while the matrix unit is busy instead of in one block.  (Pinning the
@@ -435,8 +450,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
             } else {
                 f32x2 g = gelu_tail(gv, gc, gs, gp);
                 asm volatile("" : "+v"(g));
-                pnext[I >> 3][I & 7] = (bf16)g.x;
-                pnext[I >> 3][(I & 7) + 1] = (bf16)g.y;
+                pnext[I >> 3][I & 7] = (E)g.x;
+                pnext[I >> 3][(I & 7) + 1] = (E)g.y;
             }
         };
         unrolled(std::make_integer_sequence<int, ML_PF>{}, issue);
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < ML_KS; ++t) {
-        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(vecs + 32 * t);
+        const e8 bb = *reinterpret_cast<const e8*>(vecs + 32 * t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = yacc[t >> 1][8 * (t & 1) + j] + (float)bb[j] + (float)xf[t][j];
@@ -492,13 +507,13 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
     const bool live = tok < p.M;
 #pragma unroll
     for (int t = 0; t < ML_KS; ++t) {
-        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(vecs + 2 * ML_HID + 32 * t);
-        const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(vecs + 4 * ML_HID + 32 * t);
-        bf16x8 o;
+        const e8 g8 = *reinterpret_cast<const e8*>(vecs + 2 * ML_HID + 32 * t);
+        const e8 be8 = *reinterpret_cast<const e8*>(vecs + 4 * ML_HID + 32 * t);
+        e8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            o[j] = (bf16)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
-        if (live) *reinterpret_cast<bf16x8*>(p.y + tok * ML_HID + 16 * t + 8 * h) = o;
+            o[j] = (E)((yacc[t >> 1][8 * (t & 1) + j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+        if (live) *reinterpret_cast<e8*>(p.y + tok * ML_HID + 16 * t + 8 * h) = o;
     }
 #if ML_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,25 +534,27 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParams p) {
 // start of the next one, so the wait that retires the weight loads does not wait for fresh stores.
 constexpr int LN_PF = 4;
 
-struct LinearParams {
-    const bf16* x;        // [M][384]
-    const bf16* w;        // [N][384]
-    const bf16* bias;     // [N]
-    bf16* y;              // [M][N]
+template <typename E>
+struct LinearParamsT {
+    const E* x;        // [M][384]
+    const E* w;        // [N][384]
+    const E* bias;     // [N]
+    E* y;              // [M][N]
     int64_t M;
     int N;
     // LN kernels (N == 384): y = LayerNorm(x W^T + bias + residual) * gamma + beta
-    const bf16* residual; // [M][384]
-    const bf16* gamma;    // [384]
-    const bf16* beta;     // [384]
+    const E* residual; // [M][384]
+    const E* gamma;    // [384]
+    const E* beta;     // [384]
     float eps;
 };
 
 // LN: the sum is rounded to bf16 and stored image by image while the row statistics are gathered
 // from the rounded values; a second pass over the wave's own rows (just written, still in cache)
 // normalises them in place.
-template <bool LN>
-__global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
+template <typename E, bool LN>
+__global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p) {
+    typedef typename El16<E>::x8 e8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // W images [2][32][48 x 16 B], bias fp32 [N]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,36 +580,36 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
     for (int i = 0; i < ML_W_DMAS; ++i) dma(0, 0, i);
     for (int i = tid; i < p.N; i += ML_NT) *reinterpret_cast<float*>(smem + 2 * ML_W_BYTES + 4 * i) = (float)p.bias[i];
 
-    bf16x8 xf[ML_KS];
+    e8 xf[ML_KS];
     {
-        const bf16* xrow = p.x + tok_ld * ML_HID + 8 * h;
+        const E* xrow = p.x + tok_ld * ML_HID + 8 * h;
 #pragma unroll
-        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xrow + 16 * t);
+        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
     }
     uint32_t l1[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) l1[u] = lds0 + r * (ML_HID * 2) + 16 * ((2 * u + h) ^ (r & 15));
     const unsigned char* bias_s = smem + 2 * ML_W_BYTES + 32 * h;
-    bf16* yrow = p.y + tok * p.N + 8 * h;
-    const bf16* rrow = LN ? p.residual + tok_ld * ML_HID + 8 * h : nullptr;
+    E* yrow = p.y + tok * p.N + 8 * h;
+    const E* rrow = LN ? p.residual + tok_ld * ML_HID + 8 * h : nullptr;
     float rsum = 0.f, rsq = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    bf16x8 out0, out1;                                        // the previous image's results, stored one image later
+    e8 out0, out1;                                        // the previous image's results, stored one image later
     auto image = [&](int c, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
         if (c > 0 && live) {
-            *reinterpret_cast<bf16x8*>(yrow + (c - 1) * ML_C) = out0;
-            *reinterpret_cast<bf16x8*>(yrow + (c - 1) * ML_C + 16) = out1;
+            *reinterpret_cast<e8*>(yrow + (c - 1) * ML_C) = out0;
+            *reinterpret_cast<e8*>(yrow + (c - 1) * ML_C + 16) = out1;
         }
         const int cn = min(c + 1, n_img - 1);
-        bf16x8 res0, res1;
+        e8 res0, res1;
         if constexpr (LN) {
-            res0 = *reinterpret_cast<const bf16x8*>(rrow + c * ML_C);
-            res1 = *reinterpret_cast<const bf16x8*>(rrow + c * ML_C + 16);
+            res0 = *reinterpret_cast<const e8*>(rrow + c * ML_C);
+            res1 = *reinterpret_cast<const e8*>(rrow + c * ML_C + 16);
         }
         u32x4 q[LN_PF + 1];
         f32x16 ae, ao;
@@ -606,15 +623,15 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
             if constexpr (S + LN_PF < ML_KS) issue(std::integral_constant<int, S + LN_PF>{});
             constexpr int newer = ML_KS - 1 - S < LN_PF ? ML_KS - 1 - S : LN_PF;
             lds_wait<newer>(q[S % (LN_PF + 1)]);
-            const bf16x8 a = __builtin_bit_cast(bf16x8, q[S % (LN_PF + 1)]);
+            const e8 a = __builtin_bit_cast(e8, q[S % (LN_PF + 1)]);
             if constexpr (S == 0)
-                ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[0], zero16, 0, 0, 0);
+                ae = El16<E>::mfma(a, xf[0], zero16);
             else if constexpr (S == 1)
-                ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[1], zero16, 0, 0, 0);
+                ao = El16<E>::mfma(a, xf[1], zero16);
             else if constexpr (S % 2 == 0)
-                ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[S], ae, 0, 0, 0);
+                ae = El16<E>::mfma(a, xf[S], ae);
             else
-                ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[S], ao, 0, 0, 0);
+                ao = El16<E>::mfma(a, xf[S], ao);
         };
         unrolled(std::make_integer_sequence<int, LN_PF>{}, issue);
         unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
@@ -631,8 +648,8 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
                 v0 += (float)res0[j];
                 v1 += (float)res1[j];
             }
-            out0[j] = (bf16)v0;
-            out1[j] = (bf16)v1;
+            out0[j] = (E)v0;
+            out1[j] = (E)v1;
             if constexpr (LN) {
                 const float r0 = (float)out0[j], r1 = (float)out1[j];
                 rsum += r0 + r1;
@@ -647,8 +664,8 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
         if (c + 1 < n_img) image(c + 1, std::integral_constant<int, 1>{});
     }
     if (live) {
-        *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C) = out0;
-        *reinterpret_cast<bf16x8*>(yrow + (n_img - 1) * ML_C + 16) = out1;
+        *reinterpret_cast<e8*>(yrow + (n_img - 1) * ML_C) = out0;
+        *reinterpret_cast<e8*>(yrow + (n_img - 1) * ML_C + 16) = out1;
     }
     if constexpr (LN) {
         // a token's 384 values are split between this lane and its partner in the other half-wave
@@ -660,13 +677,13 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParams p) {
         if (live) {
 #pragma unroll 4
             for (int t = 0; t < ML_KS; ++t) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(yrow + 16 * t);
-                const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(p.gamma + 16 * t + 8 * h);
-                const bf16x8 be8 = *reinterpret_cast<const bf16x8*>(p.beta + 16 * t + 8 * h);
-                bf16x8 o;
+                const e8 v = *reinterpret_cast<const e8*>(yrow + 16 * t);
+                const e8 g8 = *reinterpret_cast<const e8*>(p.gamma + 16 * t + 8 * h);
+                const e8 be8 = *reinterpret_cast<const e8*>(p.beta + 16 * t + 8 * h);
+                e8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)v[j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
-                *reinterpret_cast<bf16x8*>(yrow + 16 * t) = o;
+                for (int j = 0; j < 8; ++j) o[j] = (E)(((float)v[j] - mean) * rstd * (float)g8[j] + (float)be8[j]);
+                *reinterpret_cast<e8*>(yrow + 16 * t) = o;
             }
         }
     }
@@ -702,22 +719,23 @@ struct MlpProfile {
 };
 MlpProfile g_prof;
 
-int launch_mlp(const MlpParams& p, int mode, hipStream_t stream, const char* who) {
+template <typename E>
+int launch_mlp(const MlpParamsT<E>& p, int mode, hipStream_t stream, const char* who) {
     RAG_REQUIRE(ceil_div64(p.M, ML_BM) < (1ll << 31), RAG_ELIMIT, "%s: too many rows", who);
     const size_t lds_bytes = (size_t)ML_OFF_B1 + 4 * (size_t)p.I + 6 * ML_HID * 2;
     const int max_lds = ML_OFF_B1 + 4 * ML_MAX_I + 6 * ML_HID * 2;
-    if (mode == 1) RAG_GRANT_LDS(mlp_fused_kernel<1>, max_lds);
-    else if (mode == 2) RAG_GRANT_LDS(mlp_fused_kernel<2>, max_lds);
-    else RAG_GRANT_LDS(mlp_fused_kernel<0>, max_lds);
+    if (mode == 1) RAG_GRANT_LDS((mlp_fused_kernel<E, 1>), max_lds);
+    else if (mode == 2) RAG_GRANT_LDS((mlp_fused_kernel<E, 2>), max_lds);
+    else RAG_GRANT_LDS((mlp_fused_kernel<E, 0>), max_lds);
     const dim3 grid((unsigned)ceil_div64(p.M, ML_BM));
     const bool timed = g_prof.on && g_prof.n < MlpProfile::RING && !rag_stream_capturing(stream);
     if (timed) RAG_HIP_TRY(hipEventRecord(g_prof.ev0[g_prof.n], stream));
     if (mode == 1)
-        hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(ML_NT), lds_bytes, stream, p);
+        hipLaunchKernelGGL((mlp_fused_kernel<E, 1>), grid, dim3(ML_NT), lds_bytes, stream, p);
     else if (mode == 2)
-        hipLaunchKernelGGL(mlp_fused_kernel<2>, grid, dim3(ML_NT), lds_bytes, stream, p);
+        hipLaunchKernelGGL((mlp_fused_kernel<E, 2>), grid, dim3(ML_NT), lds_bytes, stream, p);
     else
-        hipLaunchKernelGGL(mlp_fused_kernel<0>, grid, dim3(ML_NT), lds_bytes, stream, p);
+        hipLaunchKernelGGL((mlp_fused_kernel<E, 0>), grid, dim3(ML_NT), lds_bytes, stream, p);
     RAG_HIP_TRY(hipGetLastError());
     if (timed) {
         RAG_HIP_TRY(hipEventRecord(g_prof.ev1[g_prof.n], stream));
@@ -726,12 +744,23 @@ int launch_mlp(const MlpParams& p, int mode, hipStream_t stream, const char* who
     return RAG_OK;
 }
 
+// the parameter block of the feed-forward kernels from the untyped pointers of the C ABI
+template <typename E>
+MlpParamsT<E> mlp_params(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, const void* gamma,
+                         const void* beta, void* y, int64_t m, int intermediate, float eps) {
+    MlpParamsT<E> p = {};
+    p.x = (const E*)x; p.w1 = (const E*)w1; p.b1 = (const E*)b1; p.w2 = (const E*)w2;
+    p.b2 = (const E*)b2; p.gamma = (const E*)gamma; p.beta = (const E*)beta; p.y = (E*)y;
+    p.M = m; p.I = intermediate; p.eps = eps;
+    return p;
+}
+
 }  // namespace
 
 extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                                const void* d_gamma, const void* d_beta, float eps, int64_t m, int32_t hidden,
                                int32_t intermediate, int32_t dtype, void* d_y, void* stream_) {
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_mlp: bf16 only");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_mlp: bf16 or fp16 only");
     RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
     RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
                 "rag_enc_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I, intermediate);
@@ -740,11 +769,11 @@ extern "C" int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_
     RAG_REQUIRE(d_x && d_w1 && d_b1 && d_w2 && d_b2 && d_gamma && d_beta && d_y, RAG_EINVAL, "rag_enc_mlp: null pointer");
     RAG_REQUIRE(d_x != d_y, RAG_EINVAL, "rag_enc_mlp: y must not alias x (x is read again as the residual)");
     RAG_REQUIRE(aligned16({d_x, d_w1, d_w2, d_b2, d_gamma, d_beta, d_y}), RAG_EINVAL, "rag_enc_mlp: pointers must be 16-byte aligned");
-    MlpParams p = {};
-    p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
-    p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.y = (bf16*)d_y;
-    p.M = m; p.I = intermediate; p.eps = eps;
-    return launch_mlp(p, 0, (hipStream_t)stream_, "rag_enc_mlp");
+    if (dtype == RAG_DTYPE_F16)
+        return launch_mlp(mlp_params<f16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, d_y, m, intermediate, eps), 0,
+                          (hipStream_t)stream_, "rag_enc_mlp");
+    return launch_mlp(mlp_params<bf16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, d_y, m, intermediate, eps), 0,
+                      (hipStream_t)stream_, "rag_enc_mlp");
 }
 
 extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_wo, const void* d_bo,
@@ -763,10 +792,7 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
                 RAG_EINVAL, "rag_enc_attn_out_mlp: null pointer");
     RAG_REQUIRE(aligned16({d_ctx, d_x, d_wo, d_bo, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
                 "rag_enc_attn_out_mlp: pointers must be 16-byte aligned");
-    MlpParams p = {};
-    p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
-    p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma2; p.beta = (const bf16*)d_beta2; p.y = (bf16*)d_y;
-    p.M = m; p.I = intermediate; p.eps = eps;
+    MlpParamsT<bf16> p = mlp_params<bf16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
     p.ctx = (const bf16*)d_ctx; p.wo = (const bf16*)d_wo; p.bo = (const bf16*)d_bo;
     p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
     return launch_mlp(p, 1, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
@@ -787,10 +813,7 @@ extern "C" int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const v
                 RAG_EINVAL, "rag_enc_norm_mlp: null pointer");
     RAG_REQUIRE(aligned16({d_proj, d_x, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
                 "rag_enc_norm_mlp: pointers must be 16-byte aligned");
-    MlpParams p = {};
-    p.x = (const bf16*)d_x; p.w1 = (const bf16*)d_w1; p.b1 = (const bf16*)d_b1; p.w2 = (const bf16*)d_w2;
-    p.b2 = (const bf16*)d_b2; p.gamma = (const bf16*)d_gamma2; p.beta = (const bf16*)d_beta2; p.y = (bf16*)d_y;
-    p.M = m; p.I = intermediate; p.eps = eps;
+    MlpParamsT<bf16> p = mlp_params<bf16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
     p.ctx = (const bf16*)d_proj; p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
     return launch_mlp(p, 2, (hipStream_t)stream_, "rag_enc_norm_mlp");
 }
@@ -831,7 +854,7 @@ extern "C" int rag_enc_mlp_profile_read(float* out_ms, int64_t* out_rows, int32_
 extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t n,
                                      const void* d_residual, const void* d_gamma, const void* d_beta, float eps,
                                      int32_t dtype, void* d_y, void* stream_) {
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_linear384: bf16 only");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_linear384: bf16 or fp16 only");
     RAG_REQUIRE(n >= ML_C && n % ML_C == 0 && n <= 4 * ML_MAX_I, RAG_ELIMIT,
                 "rag_enc_linear384: the output width must be a multiple of %d (got %d)", ML_C, n);
     RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_linear384: negative row count");
@@ -845,16 +868,22 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
     RAG_REQUIRE(ceil_div64(m, ML_BM) < (1ll << 31), RAG_ELIMIT, "rag_enc_linear384: too many rows");
     const size_t lds_bytes = 2 * (size_t)ML_W_BYTES + 4 * (size_t)n;
     RAG_REQUIRE(lds_bytes <= 80 * 1024, RAG_ELIMIT, "rag_enc_linear384: output width %d too large", n);
-    if (d_residual) RAG_GRANT_LDS(linear384_kernel<true>, 80 * 1024);
-    else RAG_GRANT_LDS(linear384_kernel<false>, 80 * 1024);
-    LinearParams p = {};
-    p.x = (const bf16*)d_x; p.w = (const bf16*)d_w; p.bias = (const bf16*)d_bias; p.y = (bf16*)d_y; p.M = m; p.N = n;
-    p.residual = (const bf16*)d_residual; p.gamma = (const bf16*)d_gamma; p.beta = (const bf16*)d_beta; p.eps = eps;
     const dim3 grid((unsigned)ceil_div64(m, ML_BM));
-    if (d_residual)
-        hipLaunchKernelGGL(linear384_kernel<true>, grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
-    else
-        hipLaunchKernelGGL(linear384_kernel<false>, grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+    auto launch = [&](auto elem) -> int {
+        using E = decltype(elem);
+        if (d_residual) RAG_GRANT_LDS((linear384_kernel<E, true>), 80 * 1024);
+        else RAG_GRANT_LDS((linear384_kernel<E, false>), 80 * 1024);
+        LinearParamsT<E> p = {};
+        p.x = (const E*)d_x; p.w = (const E*)d_w; p.bias = (const E*)d_bias; p.y = (E*)d_y; p.M = m; p.N = n;
+        p.residual = (const E*)d_residual; p.gamma = (const E*)d_gamma; p.beta = (const E*)d_beta; p.eps = eps;
+        if (d_residual)
+            hipLaunchKernelGGL((linear384_kernel<E, true>), grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+        else
+            hipLaunchKernelGGL((linear384_kernel<E, false>), grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+        return RAG_OK;
+    };
+    const int rc = dtype == RAG_DTYPE_F16 ? launch(f16{}) : launch(bf16{});
+    if (rc) return rc;
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

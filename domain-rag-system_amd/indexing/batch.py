@@ -72,7 +72,8 @@ class BatchSearcher:
                  fusion_method: str = 'rrf', vector_weight: float = 0.5, bm25_weight: float = 0.5,
                  ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None,
                  ce_packed=None, ce_tokens_per_batch: int = 1 << 20, ce_token_bucket: int = 1 << 17,
-                 simple_rerank: bool = False):
+                 simple_rerank: bool = False, screen_encoder=None, screen_safety: float = 1.5,
+                 screen_min_safety: float = 1.25, screen_min_pairs: int = 4096):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
@@ -95,9 +96,19 @@ class BatchSearcher:
         self.split_embed = False
         self.ce_packed = bool(ce_packed) if ce_packed is not None else (
             cross_encoder is not None and getattr(cross_encoder.bert, 'native', False)
-            and (next(cross_encoder.parameters()).dtype == torch.bfloat16
+            and (next(cross_encoder.parameters()).dtype in (torch.bfloat16, torch.float16)
                  or (next(cross_encoder.parameters()).dtype == torch.float32
                      and getattr(cross_encoder.bert, 'split_gemm', False))))
+        # Screen-then-rescore rerank (see _score_screened): `screen_encoder` is a cheap copy of the cross-encoder (the same
+        # weights in float16, one matrix-core product per product) that scores every pair; only the pairs whose cheap
+        # logit lies within a margin of their query's cheap k-th best are scored by `cross_encoder`, and the final order
+        # and rerank_score come from those exact logits alone.
+        self.screen_encoder = screen_encoder if (screen_encoder is not None and self.ce_packed) else None
+        self.screen_safety, self.screen_min_pairs = float(screen_safety), int(screen_min_pairs)
+        self.screen_min_safety = min(float(screen_min_safety), self.screen_safety)
+        self._screen_err = None                      # running estimate of the screen's error (None: the next batch rescores every pair)
+        self.screen_stats = {'pairs': 0, 'rescored': 0, 'widened': 0, 'batches': 0, 'err_max': 0.0}
+        self.last_rescored = None
         self.cls_id, self.sep_id, self.pad_id = special_ids
         self.dist = dist                                  # torch.distributed module when sharded
         self.world = dist.get_world_size() if dist is not None else 1
@@ -263,9 +274,33 @@ class BatchSearcher:
         n_pairs = b * t
         pair_query = torch.arange(b, dtype=torch.int32, device=dev).repeat_interleave(t)
         pair_row = fused_row.reshape(-1)
+        live = torch.arange(t, device=dev)[None, :] < fused_cnt[:, None]
+        screened = None
+        if (self.screen_encoder is not None and n_pairs >= self.screen_min_pairs
+                and not self._graph_ok(b, dev, self.graph_max_batch_ce)):
+            logits, screened = self._score_screened(q_tok, q_off, pair_query, pair_row, live)
+        else:
+            logits = self._score_pairs(self.cross_encoder, q_tok, q_off, pair_query, pair_row, graph_batch=b)
+        self.last_rescored = screened                 # [B, T] bool: which logits are exact ones (None: all of them)
+        # pools are the first fused_cnt[q] entries of each row: pack them back to back
+        seg_off = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
+        seg_off[1:] = torch.cumsum(fused_cnt, 0)
+        logits = logits.reshape(b, t)
+        # (a pair the screen left out keeps its cheap logit in `logits` for the record, but cannot be chosen)
+        ranked = logits if screened is None else torch.where(screened, logits, torch.full_like(logits, float('-inf')))
+        if bool((fused_cnt == t).all()):
+            flat = ranked.reshape(-1).contiguous()
+        else:
+            flat = ranked[live].contiguous()
+        idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
+        return idx, cnt, logits
+
+    def _score_pairs(self, model, q_tok, q_off, pair_query, pair_row, graph_batch=0):
+        """Logits of the given pairs (any subset, in any order) from `model`, the work split across the ranks by pair
+        index (equal shares, the last one padded, so one fixed-size all-gather returns every logit)."""
+        dev = pair_row.device
         store = self.chunk_tokens
-        # this rank's share of the pairs (pure data parallel over pair index; equal shares,
-        # the last one padded, so one fixed-size all-gather returns every logit)
+        n_pairs = pair_row.shape[0]
         share = (n_pairs + self.world - 1) // self.world
         lo, hi = min(n_pairs, share * self.rank), min(n_pairs, share * (self.rank + 1))
         my_q, my_r = pair_query[lo:hi].contiguous(), pair_row[lo:hi].contiguous()
@@ -273,29 +308,72 @@ class BatchSearcher:
         logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
-            if self.ce_packed and self._graph_ok(b, dev, self.graph_max_batch_ce) and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine):
+            if (self.ce_packed and model is self.cross_encoder and graph_batch
+                    and self._graph_ok(graph_batch, dev, self.graph_max_batch_ce)
+                    and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine)):
                 pass
             elif self.ce_packed:
-                self._ce_packed(q_tok, q_off, my_q, my_r, plen, logits_mine)
+                self._ce_packed(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
             else:
-                self._ce_padded(q_tok, q_off, my_q, my_r, plen, logits_mine)
+                self._ce_padded(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
         if self.sharded:
             gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
             self._all_gather(gathered, logits_mine)
-            logits = gathered[:n_pairs]
-        else:
-            logits = logits_mine
-        # pools are the first fused_cnt[q] entries of each row: pack them back to back
-        seg_off = torch.zeros((b + 1,), dtype=torch.int32, device=dev)
-        seg_off[1:] = torch.cumsum(fused_cnt, 0)
-        logits = logits.reshape(b, t)
-        if bool((fused_cnt == t).all()):
-            flat = logits.reshape(-1).contiguous()
-        else:
-            keep = torch.arange(t, device=dev)[None, :] < fused_cnt[:, None]
-            flat = logits[keep].contiguous()
-        idx, cnt = rag_hip.topk_segmented_dev(flat, seg_off, self.top_k)
-        return idx, cnt, logits
+            return gathered[:n_pairs]
+        return logits_mine
+
+    def _score_screened(self, q_tok, q_off, pair_query, pair_row, live):
+        """Screen, then rescore.  Returns (logits [B, T] float32: exact where `rescored`, the screen's elsewhere;
+        rescored [B, T] bool).  The exact top k of a query is certain to lie among its rescored pairs when every pair's
+        cheap logit is within e of its exact one up to an offset c common to the query's pairs (which moves no order):
+        a pair left out has a cheap logit below kth_cheap - 2 s e, hence an exact one below kth_cheap - 2 s e + e - c,
+        while each of the k cheap-best has an exact logit of at least kth_cheap - e - c.  e is not known beforehand: it
+        is measured on the pairs that were rescored (thousands per batch, every one of which has both logits): the
+        margin is 2 * screen_safety * (the running estimate of e), and when the batch's own e shows that this was less
+        than 2 * screen_min_safety * e, the margin is widened to 2 * screen_safety * e and the additional pairs are
+        rescored, so that a margin of at least 2 * screen_min_safety * e holds for every batch that is returned.  Sharded:
+        the cheap logits are gathered first, every rank takes the same decisions, and the chosen pairs are split
+        across the ranks."""
+        b, t = live.shape
+        k = min(self.top_k, t)
+        cheap = self._score_pairs(self.screen_encoder, q_tok, q_off, pair_query, pair_row).reshape(b, t)
+        cheap_live = torch.where(live, cheap, torch.full_like(cheap, float('-inf')))
+        kth = torch.topk(cheap_live, k, dim=1).values[:, k - 1:k]               # -inf where a pool has fewer than k pairs
+        exact = cheap.clone()
+        rescored = torch.zeros_like(live)
+        margin = float('inf') if self._screen_err is None else 2.0 * self.screen_safety * self._screen_err
+        widened = 0
+
+        def rescore(mask):
+            sel = torch.nonzero(mask.reshape(-1))[:, 0]
+            if sel.numel():
+                exact.view(-1)[sel] = self._score_pairs(self.cross_encoder, q_tok, q_off, pair_query[sel].contiguous(),
+                                                        pair_row[sel].contiguous())
+        while True:
+            want = live & ~rescored & ((cheap_live >= kth - margin) | torch.isinf(kth))
+            rescore(want)
+            rescored |= want
+            # what the margin should have been, from the pairs that now have both logits
+            d = torch.where(rescored, cheap - exact, torch.full_like(cheap, float('nan')))
+            resid = (d - torch.nanmedian(d, dim=1, keepdim=True).values).abs()
+            err = float(torch.nan_to_num(resid, nan=0.0).max())
+            if 2.0 * self.screen_min_safety * err <= margin or bool((rescored | ~live).all()):
+                break
+            if widened >= 3:                         # still too small after three rounds: take no chances
+                rest = live & ~rescored
+                rescore(rest)
+                rescored |= rest
+                break
+            margin = 2.0 * self.screen_safety * err
+            widened += 1
+        self._screen_err = err if self._screen_err is None else max(err, 0.97 * self._screen_err)
+        st = self.screen_stats
+        st['pairs'] += int(live.sum())
+        st['rescored'] += int(rescored.sum())
+        st['widened'] += widened
+        st['batches'] += 1
+        st['err_max'] = max(st['err_max'], err)
+        return exact, rescored
 
     def _ce_graphed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
         """Packing and the cross-encoder forward of a very small batch as one captured HIP graph.  Static shapes, chosen
@@ -335,7 +413,7 @@ class BatchSearcher:
         logits_mine[:n] = g(qt, q_off, my_r)
         return True
 
-    def _ce_padded(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+    def _ce_padded(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine):
         """Pairs sorted by length, padded mini-batches (any model dtype, PyTorch or native ops)."""
         store = self.chunk_tokens
         n_mine = my_r.shape[0]
@@ -354,22 +432,22 @@ class BatchSearcher:
             ids, types, mask = rag_hip.ce_pack_dev(
                 q_tok, q_off, store.tok, store.off, store.row_base, my_q[idx].contiguous(),
                 my_r[idx].contiguous(), None, s1 - s0, seq, self.cls_id, self.sep_id, self.pad_id)
-            out = self.cross_encoder(ids, types, mask)
+            out = model(ids, types, mask)
             logits_mine[idx] = out.float()
 
-    def _ce_packed(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+    def _ce_packed(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine):
         """Longest pairs first: a mini-batch then holds pairs of similar length, and the attention kernel,
         whose LDS image is sized by the mini-batch's longest pair, fits more workgroups per compute unit on
         all but the first one.  A pair's logit does not depend on its place in the stream."""
         if not self.ce_sort_by_length or my_r.shape[0] < 2:
-            return self._ce_packed_stream(q_tok, q_off, my_q, my_r, plen, logits_mine)
+            return self._ce_packed_stream(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
         order = torch.argsort(plen, descending=True, stable=True)
         sorted_logits = torch.zeros_like(logits_mine)
-        self._ce_packed_stream(q_tok, q_off, my_q[order].contiguous(), my_r[order].contiguous(),
+        self._ce_packed_stream(model, q_tok, q_off, my_q[order].contiguous(), my_r[order].contiguous(),
                                plen[order].contiguous(), sorted_logits)
         logits_mine[order] = sorted_logits
 
-    def _ce_packed_stream(self, q_tok, q_off, my_q, my_r, plen, logits_mine):
+    def _ce_packed_stream(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine):
         """Pairs in the given order as unpadded token streams: no padding inside a pair is
         computed at all (bfloat16 model, librag_hip encoder kernels).  The stream is cut at
         pair boundaries into mini-batches of at most `ce_tokens_per_batch` tokens, each rounded
@@ -383,9 +461,9 @@ class BatchSearcher:
         cu_all[1:] = torch.cumsum(plen, 0)
         cu_host = cu_all.cpu().numpy()                   # the one host copy of the stage
         budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
-        cb = self.cross_encoder.bert
+        cb = model.bert
         own_gemms = (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
-                     and cb.word.weight.dtype == torch.bfloat16 and cb.config.hidden_size == 384)
+                     and cb.word.weight.dtype in (torch.bfloat16, torch.float16) and cb.config.hidden_size == 384)
         mixed_gemms = cb.word.weight.dtype == torch.float32 and getattr(cb, 'split_gemm', False)
         if own_gemms or mixed_gemms:
             # every GEMM of the layers is one of the library's own kernels, which take any row count, or a
@@ -424,11 +502,11 @@ class BatchSearcher:
                                                              my_q[p0:p1], my_r[p0:p1], cu, total, self.ce_max_len,
                                                              self.cls_id, self.sep_id, padded_total=padded)
                 if int(np.count_nonzero(cu_host[p0 + 1:p1 + 1] == cu_host[p0:p1])) == 0:
-                    logits_mine[p0:p1] = self.cross_encoder.forward_packed(ids, types, pos, cu, longest)
+                    logits_mine[p0:p1] = model.forward_packed(ids, types, pos, cu, longest)
                 else:                                    # empty slots (row -1) have no tokens and no logit
                     keep = torch.nonzero(lens > 0)[:, 0]
                     cu_live = torch.cat([cu[:-1][keep], cu[-1:]])
-                    logits_mine[p0 + keep] = self.cross_encoder.forward_packed(ids, types, pos, cu_live, longest)
+                    logits_mine[p0 + keep] = model.forward_packed(ids, types, pos, cu_live, longest)
             p0 = p1
         if n_streams > 1:
             for st in self._ce_stream_pool[:n_streams]:

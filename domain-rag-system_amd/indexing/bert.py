@@ -184,7 +184,7 @@ class BertEncoder(nn.Module):
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
         for li, l in enumerate(self.layers):
-            if first_token_only and li == last and x.dtype == torch.bfloat16:
+            if first_token_only and li == last and x.dtype in (torch.bfloat16, torch.float16):
                 ctx = rag_hip.enc_attention_packed_first_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
                 x = x[cu_seqlens[:-1].long()]
                 if self._layer_tail_fused(l, x):
@@ -228,7 +228,7 @@ class BertEncoder(nn.Module):
         import rag_hip
         return (self.fused_mlp and self.fused_tail and l.attn_norm.eps == l.ffn_norm.eps
                 and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight)
-                and l.attn_out.weight.dtype == torch.bfloat16)
+                and l.attn_out.weight.dtype == torch.bfloat16)     # (the fused tail kernels are bfloat16 only)
 
     def _norm_mlp_fused(self, l, x, ctx):
         import rag_hip
@@ -502,7 +502,7 @@ class CrossEncoderModel(nn.Module):
     def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
         """Logits of an unpadded batch (every sequence non-empty, first token [CLS])."""
         b = self.bert
-        if b.word.weight.dtype == torch.bfloat16 or (b.split_gemm and b.fused_split_tails):
+        if b.word.weight.dtype in (torch.bfloat16, torch.float16) or (b.split_gemm and b.fused_split_tails):
             cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True)
         else:
             cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)[cu_seqlens[:-1].long()]
@@ -607,7 +607,37 @@ def _resolve_dir(spec):
             f"({type(e).__name__}); pass a directory or a 'random:<arch>' spec") from e
 
 
-def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False, split_dtype=None):
+# Weight initialisations of the `random:<arch>` models.  'hf-default' is what transformers gives an untrained model
+# (every matrix N(0, 0.02), no biases, unit LayerNorm gains): attention is nearly uniform and the 50 logits of a query
+# differ by ~1e-3.  'trained-scale' has the magnitudes of a trained checkpoint (matrix gains around one, biases,
+# LayerNorm gains spread around one), so that every term of the forward moves the output and logits spread over units.
+INITS = ('hf-default', 'trained-scale')
+
+
+def _init_random(model, kind, seed, init):
+    gen = torch.Generator().manual_seed(seed + (0 if kind == 'bi' else 1))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if init == 'hf-default':
+                if name.endswith('norm.weight'):
+                    p.fill_(1.0)
+                elif name.endswith('bias'):
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+            else:
+                if name.endswith('norm.weight'):
+                    p.copy_(1.0 + 0.3 * torch.randn(p.shape, generator=gen))
+                elif name.endswith('bias'):
+                    p.copy_(0.2 * torch.randn(p.shape, generator=gen))
+                elif p.dim() == 2 and name.split('.')[-2] in ('word', 'position', 'token_type'):
+                    p.copy_(0.5 * torch.randn(p.shape, generator=gen))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=gen) / math.sqrt(p.shape[-1]))
+
+
+def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, split_gemm=False, split_dtype=None,
+               init='hf-default'):
     """kind: 'bi' or 'cross'.  Returns (module in eval mode on `device`, tokenizer, config).
     native=True runs attention and residual+LayerNorm through the librag_hip kernels (GPU,
     bfloat16 or float32, left-aligned attention masks; shapes they do not cover raise);
@@ -615,7 +645,7 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
     cover.  split_gemm=True (float32 weights, packed forward) runs the GEMMs and attention as
     split-precision products on the 16-bit matrix cores with fp32 accumulation; split_dtype =
     torch.bfloat16 (default: results to ~1e-5 relative) or torch.float16 (to fp32 round-off;
-    activations and weights must stay below 65504)."""
+    activations and weights must stay below 65504).  init: how a `random:` model's weights are drawn (INITS)."""
     cls = BiEncoder if kind == 'bi' else CrossEncoderModel
     if spec.startswith('random:'):
         arch = spec.split(':', 1)[1]
@@ -623,15 +653,9 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
             raise ValueError(f"unknown random architecture {arch!r}; known: {sorted(ARCHS)}")
         cfg = ARCHS[arch]
         model = cls(cfg)
-        gen = torch.Generator().manual_seed(seed + (0 if kind == 'bi' else 1))
-        with torch.no_grad():
-            for name, p in model.named_parameters():
-                if name.endswith('norm.weight'):
-                    p.fill_(1.0)
-                elif name.endswith('bias'):
-                    p.zero_()
-                else:
-                    p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+        if init not in INITS:
+            raise ValueError(f"unknown initialisation {init!r}; known: {INITS}")
+        _init_random(model, kind, seed, init)
         tok = HashTokenizer(cfg.vocab_size)
     else:
         directory = _resolve_dir(spec)
@@ -645,7 +669,7 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
         tok = FileTokenizer(directory)
     model.eval().to(device=device, dtype=dtype)
     if native == 'auto':            # on the GPU whenever the kernels cover the architecture
-        native = (torch.device(device).type == 'cuda' and dtype in (torch.bfloat16, torch.float32)
+        native = (torch.device(device).type == 'cuda' and dtype in (torch.bfloat16, torch.float16, torch.float32)
                   and cfg.hidden_size // cfg.num_attention_heads in (32, 64))
     model.bert.native = bool(native)
     model.bert.split_gemm = bool(split_gemm)

@@ -717,16 +717,23 @@ def ce_pack_dev(query_tok, query_off, chunk_tok, chunk_off, chunk_row_base, pair
 # ---- transformer encoder pieces ----------------------------------------------------------------
 def enc_attention_supported(dtype, head_dim, seq_len):
     import torch
-    return dtype in (torch.bfloat16, torch.float32) and head_dim in (32, 64) and seq_len <= ENC_MAX_SEQ
+    return dtype in (torch.bfloat16, torch.float16, torch.float32) and head_dim in (32, 64) and seq_len <= ENC_MAX_SEQ
 
 
 def _enc_dtype(t):
     import torch
     if t.dtype == torch.bfloat16:
         return DTYPE_BF16
+    if t.dtype == torch.float16:
+        return DTYPE_F16
     if t.dtype == torch.float32:
         return DTYPE_F32
-    raise ValueError(f"the encoder kernels handle bfloat16 and float32, not {t.dtype}")
+    raise ValueError(f"the encoder kernels handle bfloat16, float16 and float32, not {t.dtype}")
+
+
+def _is_16bit(dtype):
+    import torch
+    return dtype in (torch.bfloat16, torch.float16)
 
 
 def enc_attention_dev(qkv, lens, n_heads):
@@ -747,8 +754,8 @@ def enc_attention_dev(qkv, lens, n_heads):
 def enc_add_layernorm_dev(x, residual, gamma, beta, eps):
     """LayerNorm(x + residual) over the last dimension, one kernel (rag_enc_add_layernorm_dev)."""
     import torch
-    if x.dtype not in (torch.bfloat16, torch.float32):
-        raise ValueError("enc_add_layernorm_dev handles bfloat16 and float32")
+    if x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise ValueError("enc_add_layernorm_dev handles bfloat16, float16 and float32")
     hidden = x.shape[-1]
     rows = x.numel() // hidden
     if residual is not None and residual.shape != x.shape:
@@ -757,7 +764,7 @@ def enc_add_layernorm_dev(x, residual, gamma, beta, eps):
         raise ValueError("gamma and beta must have one entry per hidden unit")
     out = torch.empty_like(x)
     check(lib().rag_enc_add_layernorm_dev(_ptr(x), _ptr(residual, x.dtype), _ptr(gamma, x.dtype), _ptr(beta, x.dtype),
-                                          float(eps), rows, hidden, DTYPE_BF16 if x.dtype == torch.bfloat16 else DTYPE_F32,
+                                          float(eps), rows, hidden, _enc_dtype(x),
                                           _ptr(out), _stream()), 'rag_enc_add_layernorm_dev')
     return out
 
@@ -783,15 +790,15 @@ def enc_embed_layernorm_dev(ids, types, pos, word, position, type_emb, gamma, be
     t = ids.shape[0]
     hidden = word.shape[1]
     dt = word.dtype
-    if dt not in (torch.bfloat16, torch.float32):
-        raise ValueError("enc_embed_layernorm_dev handles bfloat16 and float32 tables")
+    if dt not in (torch.bfloat16, torch.float16, torch.float32):
+        raise ValueError("enc_embed_layernorm_dev handles bfloat16, float16 and float32 tables")
     if tuple(pos.shape) != (t,) or (types is not None and tuple(types.shape) != (t,)):
         raise ValueError("ids, types and pos must have one entry per token")
     out = torch.empty((t, hidden), dtype=dt, device=ids.device)
     check(lib().rag_enc_embed_layernorm_dev(_ptr(ids, torch.int32), _ptr(types, torch.int32), _ptr(pos, torch.int32),
                                             _ptr(word), _ptr(position, dt), _ptr(type_emb, dt), _ptr(gamma, dt),
                                             _ptr(beta, dt), float(eps), t, hidden, word.shape[0], position.shape[0],
-                                            type_emb.shape[0], DTYPE_BF16 if dt == torch.bfloat16 else DTYPE_F32,
+                                            type_emb.shape[0], _enc_dtype(word),
                                             _ptr(out), _stream()), 'rag_enc_embed_layernorm_dev')
     return out
 
@@ -910,15 +917,17 @@ def split_weight_bf16x3(w, half=None):
 
 
 def enc_attention_packed_first_dev(qkv, cu_seqlens, max_seq_len, n_heads):
-    """Attention output of the first token of every sequence only: qkv [T, 3*H] bf16 ->
+    """Attention output of the first token of every sequence only: qkv [T, 3*H] bf16 or fp16 ->
     [n_seq, H] (rag_enc_attention_packed_first_dev)."""
     import torch
+    if not _is_16bit(qkv.dtype):
+        raise ValueError("enc_attention_packed_first_dev handles bfloat16 and float16")
     t, h3 = qkv.shape
     hidden = h3 // 3
     n_seq = cu_seqlens.shape[0] - 1
     out = torch.empty((n_seq, hidden), dtype=qkv.dtype, device=qkv.device)
-    check(lib().rag_enc_attention_packed_first_dev(_ptr(qkv, torch.bfloat16), _ptr(cu_seqlens, torch.int32), n_seq, t,
-                                                   int(max_seq_len), int(n_heads), hidden // int(n_heads), DTYPE_BF16,
+    check(lib().rag_enc_attention_packed_first_dev(_ptr(qkv), _ptr(cu_seqlens, torch.int32), n_seq, t,
+                                                   int(max_seq_len), int(n_heads), hidden // int(n_heads), _enc_dtype(qkv),
                                                    _ptr(out), _stream()), 'rag_enc_attention_packed_first_dev')
     return out
 
@@ -972,13 +981,13 @@ def enc_gelu_(x):
 
 def enc_mlp_supported(x, w1, w2):
     import torch
-    return (x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    return (_is_16bit(x.dtype) and w1.dtype == x.dtype and w2.dtype == x.dtype
             and x.shape[-1] == 384 and w1.shape[1] == 384 and w1.shape[0] % 32 == 0)
 
 
 def enc_mlp_dev(x, w1, b1, w2, b2, gamma, beta, eps=1e-12):
     """LayerNorm(x + GELU(x @ w1.T + b1) @ w2.T + b2) * gamma + beta in one kernel
-    (rag_enc_mlp_dev); x [M, 384] bf16, w1 [I, 384], w2 [384, I]."""
+    (rag_enc_mlp_dev); x [M, 384] bf16 or fp16 (every operand of that type), w1 [I, 384], w2 [384, I]."""
     import torch
     m, hid = x.shape
     inter = w1.shape[0]
@@ -987,21 +996,23 @@ def enc_mlp_dev(x, w1, b1, w2, b2, gamma, beta, eps=1e-12):
     if tuple(b2.shape) != (hid,) or tuple(gamma.shape) != (hid,) or tuple(beta.shape) != (hid,):
         raise ValueError("b2, gamma and beta must be [H]")
     y = torch.empty_like(x)
-    bf = torch.bfloat16
+    bf = x.dtype
+    if not _is_16bit(bf):
+        raise ValueError("enc_mlp_dev handles bfloat16 and float16")
     check(lib().rag_enc_mlp_dev(_ptr(x, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma, bf),
-                                _ptr(beta, bf), float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()),
+                                _ptr(beta, bf), float(eps), m, hid, inter, _enc_dtype(x), _ptr(y), _stream()),
           'rag_enc_mlp_dev')
     return y
 
 
 def enc_linear384_supported(x, weight):
     import torch
-    return (x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] == 384
+    return (_is_16bit(x.dtype) and weight.dtype == x.dtype and x.shape[-1] == 384
             and weight.shape[1] == 384 and weight.shape[0] % 32 == 0 and weight.shape[0] <= 6144)
 
 
 def enc_linear384_dev(x, weight, bias, residual=None, gamma=None, beta=None, eps=1e-12):
-    """x @ weight.T + bias for 384-wide bf16 inputs (rag_enc_linear384_dev); x [M, 384], weight [N, 384].
+    """x @ weight.T + bias for 384-wide bf16 or fp16 inputs (rag_enc_linear384_dev); x [M, 384], weight [N, 384].
     With ``residual`` [M, 384] (N == 384): LayerNorm(that + residual) * gamma + beta."""
     import torch
     m, k = x.shape
@@ -1011,10 +1022,12 @@ def enc_linear384_dev(x, weight, bias, residual=None, gamma=None, beta=None, eps
     if residual is not None and (n != 384 or tuple(residual.shape) != (m, 384) or gamma is None or beta is None
                                  or tuple(gamma.shape) != (384,) or tuple(beta.shape) != (384,)):
         raise ValueError("the LayerNorm tail needs N == 384, residual [M, 384], gamma [384] and beta [384]")
-    y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
-    bf = torch.bfloat16
+    bf = x.dtype
+    if not _is_16bit(bf):
+        raise ValueError("enc_linear384_dev handles bfloat16 and float16")
+    y = torch.empty((m, n), dtype=bf, device=x.device)
     check(lib().rag_enc_linear384_dev(_ptr(x, bf), _ptr(weight, bf), _ptr(bias, bf), m, n, _ptr(residual, bf),
-                                      _ptr(gamma, bf), _ptr(beta, bf), float(eps), DTYPE_BF16, _ptr(y), _stream()),
+                                      _ptr(gamma, bf), _ptr(beta, bf), float(eps), _enc_dtype(x), _ptr(y), _stream()),
           'rag_enc_linear384_dev')
     return y
 

@@ -61,8 +61,8 @@ def test_default_rows_make_eight_gpus_the_ten_million_row_configuration():
 @pytest.mark.gpu
 def test_gpus_1_through_the_launcher_over_rccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', '20000', '--batch', '64',
-                        '--no-extras', '--cpu-queries', '0', '--steps', '2', '--warmup', '1', '--embed-arch', 'tiny',
-                        '--vocab', '5000'],
+                        '--no-extras', '--cpu-queries', '0', '--steps', '2', '--warmup', '1', '--embed-arch', 'minilm-l6',
+                        '--dim', '384', '--vocab', '5000'],
                        capture_output=True, text=True, timeout=600, env=_clean_env(RAG_DIST_FORCE='1'))
     assert p.returncode == 0, p.stderr[-3000:]
     line = _line(p.stdout)

@@ -55,7 +55,7 @@ def test_attention_argument_errors():
     with pytest.raises(rag_hip.RagHipError):
         rag_hip.enc_attention_dev(qkv, lens, 3)          # head size 16
     with pytest.raises(ValueError):
-        rag_hip.enc_attention_dev(qkv.half(), lens, 1)      # fp16 is not covered
+        rag_hip.enc_attention_dev(qkv.double(), lens, 1)    # float64 is not covered
     big = torch.zeros((1, 513, 3 * 32), dtype=torch.bfloat16, device=dev)
     with pytest.raises(rag_hip.RagHipError):
         rag_hip.enc_attention_dev(big, lens, 1)
@@ -466,3 +466,28 @@ def test_embed_layernorm_split_equals_the_two_passes(half):
     rag_hip.check_faults()
     with pytest.raises(ValueError):
         rag_hip.enc_embed_layernorm_split_dev(ids, types, pos, word.bfloat16(), position, type_emb, gamma, beta, 1e-12, half)
+
+
+def test_float16_cross_encoder_with_native_kernels_is_eight_times_closer_than_bfloat16():
+    """The float16 instances of the 16-bit kernels (the screening pass of the rerank): packed forward against the
+    float32 PyTorch forward, beside the bfloat16 instances on the same pairs."""
+    from indexing import bert
+    dev = torch.device('cuda:0')
+    ref, _, cfg = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float32, init='trained-scale')
+    f16, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float16, native=True, init='trained-scale')
+    b16, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.bfloat16, native=True, init='trained-scale')
+    g = torch.Generator(device=dev).manual_seed(9)
+    b, s = 96, 120
+    ids = torch.randint(1000, cfg.vocab_size, (b, s), generator=g, device=dev)
+    lens = torch.randint(5, s + 1, (b,), generator=g, device=dev)
+    mask = (torch.arange(s, device=dev)[None, :] < lens[:, None]).long()
+    types = (torch.arange(s, device=dev)[None, :] >= (lens[:, None] // 3)).long() * mask
+    p_ids, p_types, p_pos, cu, longest = ref.bert.pack(ids, mask, types)
+    with torch.no_grad():
+        a = ref(ids, types, mask)
+        h = f16.forward_packed(p_ids, p_types, p_pos, cu, longest)
+        l = b16.forward_packed(p_ids, p_types, p_pos, cu, longest)
+    torch.cuda.synchronize()
+    e16, eb = float((h - a).abs().max()), float((l - a).abs().max())
+    assert h.dtype == torch.float32 and e16 < 0.35 * eb, (e16, eb)
+    assert e16 < 0.02 * float(a.std()) + 1e-3, (e16, float(a.std()))

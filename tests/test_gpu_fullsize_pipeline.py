@@ -35,9 +35,9 @@ def shard():
     bm25.close()
 
 
-def _searcher(sh, ce, top_n):
+def _searcher(sh, ce, top_n, screen=None):
     from indexing.batch import BatchSearcher, TokenStore
-    return BatchSearcher(sh['dense'], sh['bm25'], canon=sh['canon'], bi_encoder=sh['bi'], cross_encoder=ce,
+    return BatchSearcher(sh['dense'], sh['bm25'], canon=sh['canon'], bi_encoder=sh['bi'], cross_encoder=ce, screen_encoder=screen,
                          chunk_tokens=TokenStore(sh['tok'], sh['off'], 0), top_k=5, rerank_top_n=top_n)
 
 
@@ -120,6 +120,27 @@ def test_hybrid_cross_encoder_top5_equals_the_fp32_forward_at_config_size(shard)
     assert excused <= 64
     # rerank scores of the returned entries are the float32 logits
     assert float((fast['rerank_score'][same] - ref['rerank_score'][same]).abs().max()) < 5e-6
+
+    # the default of the timed path: every pair screened by a float16 forward, the pairs near each query's top 5 rescored
+    # by the float32-equivalent forward.  Same bar, same eps: 0 unexcused; scores of the returned entries exact.
+    # (two batches: the first has no error estimate and rescores every pair, the second is the screened one)
+    ce_h, _, _ = bert.load_model('random:minilm-l6', 'cross', dev, dtype=torch.float16, native=True)
+    s_scr = _searcher(sh, ce_fast, 50, screen=ce_h)
+    _run(s_scr, sh['q'])
+    assert s_scr.last_rescored is not None and bool(s_scr.last_rescored.all())
+    scr = _run(s_scr, sh['q'])
+    mask = s_scr.last_rescored
+    frac = float(mask.float().mean())
+    same_s = (scr['rows'] == ref['rows']).all(dim=1)
+    unexcused_s = int((~same_s & (gap >= eps)).sum())
+    print(f'config 4, screened: {int(same_s.sum())}/1024 top-5 lists identical, {unexcused_s} unexcused, '
+          f'{frac:.3f} of the pairs rescored, within-query screen error {s_scr._screen_err:.2e}')
+    assert unexcused_s == 0 and int((~same_s).sum()) <= 64
+    assert float((scr['logits'] - ref['logits'])[mask].abs().max()) < 5e-6
+    assert float((scr['rerank_score'][same_s] - ref['rerank_score'][same_s]).abs().max()) < 5e-6
+    assert bool(torch.gather(mask, 1, torch.topk(ref['logits'], 5, dim=1).indices).all())      # the true top 5 were rescored
+    assert frac < 0.5
+    assert torch.equal(scr['rows'], fast['rows'])    # and the very lists of the unscreened path
 
     # the bfloat16 kernels on the same inputs: logits good to bf16 precision only, so the order among
     # candidates whose float32 logits differ by less than that is not held (reported, not asserted equal)

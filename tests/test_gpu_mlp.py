@@ -338,3 +338,39 @@ def test_linear_ln_split_argument_errors_and_row_independence():
     with pytest.raises(ValueError):
         rag_hip.enc_linear_ln_split_dev(h, b1, wh, wl, b2, res[:10], gamma, beta, 1e-12)
     rag_hip.check_faults()
+
+
+@pytest.mark.parametrize('m,inter', [(1000, 1536), (1, 1536), (129, 64)])
+def test_mlp_block_float16_instance_matches_exact(m, inter):
+    """The same kernel with float16 elements (the cross-encoder's screening pass): 11 significant bits instead of 8."""
+    import rag_hip
+    args = [a.float().to(torch.float16) for a in _layer(m, inter, 11 * m + inter)]
+    y = rag_hip.enc_mlp_dev(*args, 1e-12)
+    assert y.dtype == torch.float16
+    ref = _exact(*args)
+    err = (y.double() - ref).abs()
+    assert float(err.max()) < 6e-3 and float(err.mean()) < 6e-4          # an eighth of the bfloat16 bounds
+    bf = rag_hip.enc_mlp_dev(*[a.to(torch.bfloat16) for a in args], 1e-12)
+    assert float(err.mean()) < 0.3 * float((bf.double() - ref).abs().mean())
+
+
+@pytest.mark.parametrize('m,n', [(1000, 1152), (1, 32), (77, 384)])
+def test_linear384_float16_instance_matches_exact(m, n):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(5 * m + n)
+    h = torch.float16
+    x = torch.randn((m, 384), generator=g, device=dev).to(h)
+    w = (torch.randn((n, 384), generator=g, device=dev) * 0.05).to(h)
+    b = (torch.randn((n,), generator=g, device=dev) * 0.1).to(h)
+    y = rag_hip.enc_linear384_dev(x, w, b)
+    assert y.dtype == h
+    ref = x.double() @ w.double().t() + b.double()
+    assert float(((y.double() - ref).abs() / (ref.abs() + 1.0)).max()) < 8e-4
+    if n == 384:
+        gamma = (1 + 0.1 * torch.randn((384,), generator=g, device=dev)).to(h)
+        beta = (0.1 * torch.randn((384,), generator=g, device=dev)).to(h)
+        res = torch.randn((m, 384), generator=g, device=dev).to(h)
+        y2 = rag_hip.enc_linear384_dev(x, w, b, res, gamma, beta, 1e-12)
+        ref2 = torch.nn.functional.layer_norm(ref + res.double(), (384,), gamma.double(), beta.double(), 1e-12)
+        assert float((y2.double() - ref2).abs().max()) < 8e-3
