@@ -700,6 +700,117 @@ def main():
                 'top_k_ids_identical_to_fp32': '%d/%d' % (int(same_h.sum()), int(same_h.numel())),
                 'max_abs_logit_error': float((o_h['logits'].double() - o_ref['logits'].double()).abs().max())}
             del s_h
+        # ---- the two configurations in which the retrieval kernels ARE the step --------------------------------------
+        def timed_ms(fn, reps):
+            """average milliseconds of fn() over reps calls, by HIP events on the current stream (after one untimed call)"""
+            fn()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b_.record()
+            b_.synchronize()
+            return a.elapsed_time(b_) / reps
+
+        def scan_roofline(index, n_rows, batch, ms):
+            fl = 2.0 * n_rows * args.dim * batch
+            byt = 4.0 * n_rows * args.dim
+            r = {'kernel': 'dense scan (rag_dense_search_dev: pre-pass + main pass + list merge%s)' % (
+                     ', split-bf16 products + fp32 rescoring' if getattr(index, 'split', False) else ''),
+                 'avg_search_ms': round(ms, 4), 'unit': 'TFLOP/s' if batch >= 40 else 'GB/s'}
+            if batch >= 40:              # matrix-core bound (arithmetic intensity batch / 2 FLOP per byte)
+                split = bool(getattr(index, 'split', False))
+                peak = MFMA_BF16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+                ach = fl / (ms * 1e-3) / 1e12
+                r.update(bound='mfma', achieved=round(ach, 1), peak=peak, frac=round(ach / peak, 4), traffic=None,
+                         vs_fp32_matrix_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 3))
+                if split:
+                    r.update(executed_tflops=round(3 * ach, 1), executed_frac=round(3 * ach / peak, 4))
+            else:                        # one pass over the rows: HBM bound
+                ach = byt / (ms * 1e-3) / 1e9
+                r.update(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                         note='algorithmic bytes = 4 x rows x dim per search' + (
+                             '; %d MB of rows fit the 256 MB memory-side cache, so repeated searches need not reach HBM'
+                             % (byt / 1e6) if byt < 256e6 * 1.5 else ''))
+            return r
+
+        # BASELINE configs[1]: 100k x 768, embed + brute-force cosine kNN top_k=10 (VectorIndexer.search,
+        # reference src/indexing/vector_indexer.py:165-230), no BM25, no fusion, no reranker
+        n2 = min(100_000, args.rows)
+        dense2 = rag_hip.DenseIndex(rows[:n2], metric='cosine', borrow=True)
+        dense2.reserve(args.batch, 10)
+        s2 = BatchSearcher(dense2, None, bi_encoder=bi, top_k=10, rerank_top_n=10)
+        q1 = make_queries(argparse.Namespace(**{**vars(args), 'batch': 1}), 6, dev, seed=411)
+
+        def knn(q):
+            return s2.dense_search(s2.embed(q['ids'], q['mask']), 10)
+        qv_b = s2.embed(queries[0]['ids'], queries[0]['mask'])
+        qv_1 = s2.embed(q1[0]['ids'], q1[0]['mask'])
+        ms_e2e = timed_ms(lambda: knn(queries[0]), 20)
+        ms_scan = timed_ms(lambda: s2.dense_search(qv_b, 10), 50)
+        for q in q1:
+            knn(q)                               # (single queries replay the embedder's HIP graph: shapes seen once first)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for q in q1:
+                knn(q)
+        torch.cuda.synchronize()
+        ms_one = (time.perf_counter() - t1) / (5 * len(q1)) * 1e3
+        ms_scan1 = timed_ms(lambda: s2.dense_search(qv_1, 10), 200)
+        extra['config_2_knn_100k'] = {
+            'workload': '%d x %d corpus, %s embed + exact cosine kNN top_k=10' % (n2, args.dim, args.embed_arch),
+            'value': round(args.batch / ms_e2e * 1e3, 1), 'unit': 'queries/sec', 'batch': args.batch,
+            'ms_per_step': round(ms_e2e, 3), 'embed_ms': round(ms_e2e - ms_scan, 3),
+            'single_query_latency_ms': round(ms_one, 3),
+            'roofline': scan_roofline(dense2, n2, args.batch, ms_scan),
+            'roofline_single_query': scan_roofline(dense2, n2, 1, ms_scan1)}
+        del s2
+        dense2.close()
+        # BASELINE configs[2]: 1M x 768, hybrid vector + BM25 with RRF, top_k=5, no reranker
+        # (HybridIndexer.search, reference src/indexing/hybrid_indexer.py:60-110: 2 x top_k entries per list)
+        s3 = BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, top_k=args.top_k, rerank_top_n=args.top_k)
+        v, ms = time_steps(s3, queries[:nx])
+        k3 = 2 * args.top_k
+        q0 = queries[0]
+        qv3 = s3.embed(q0['ids'], q0['mask'])
+        ms_d = timed_ms(lambda: s3.dense_search(qv3, k3), 20)
+        ms_b = timed_ms(lambda: s3.bm25_search(q0['qterms'], q0['qoff'], q0['n_terms'], k3), 20)
+        vec3, bm3 = s3.dense_search(qv3, k3), s3.bm25_search(q0['qterms'], q0['qoff'], q0['n_terms'], k3)
+        ms_f = timed_ms(lambda: s3.fuse(vec3, bm3, args.top_k), 50)
+        tq = q0['host']['terms']
+        tq = tq[tq >= 0].astype(np.int64)                       # (out-of-vocabulary tokens have no postings)
+        ip = np.asarray(host['arr'].indptr)
+        postings = float((ip[tq + 1] - ip[tq]).sum())
+        one3 = make_queries(argparse.Namespace(**{**vars(args), 'batch': 1}), 6, dev, seed=431)
+        _, ms_one3 = time_steps(s3, one3, n_warm=len(one3))
+        bm_pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_bm25_sq.json')
+        if not os.path.exists(bm_pmc):
+            bm_pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_bm25_sq.json')
+        issue = None
+        if os.path.exists(bm_pmc):
+            with open(bm_pmc) as f:
+                pm = json.load(f)
+            ps = pm.get('per_search', {})
+            issue = {'source': os.path.relpath(bm_pmc, ROOT), 'workload': pm.get('workload'),
+                     'wave_time_shares': pm.get('wave_time_shares'),
+                     'lds_bank_conflict_share_of_lds_active_cycles': (
+                         round(ps['SQ_LDS_BANK_CONFLICT'] / ps['SQ_ACTIVE_INST_LDS'], 3)
+                         if ps.get('SQ_ACTIVE_INST_LDS') else None)}
+        extra['config_3_hybrid_rrf_1m'] = {
+            'workload': '%d x %d corpus, hybrid vector + BM25, RRF, top_k=%d, no reranker' % (args.rows, args.dim, args.top_k),
+            'value': v, 'unit': 'queries/sec', 'batch': args.batch, 'ms_per_step': ms,
+            'single_query_latency_ms': ms_one3,
+            'stage_ms': {'dense': round(ms_d, 3), 'bm25': round(ms_b, 3), 'fuse': round(ms_f, 3)},
+            'roofline_dense_scan': scan_roofline(dense, args.rows, args.batch, ms_d),
+            'bm25': {'kernel': 'bm25_tile_kernel (+ offsets, sample pass, list merges)', 'us_per_query': round(ms_b * 1e3 / args.batch, 3),
+                     'postings_per_query': round(postings / args.batch, 1),
+                     'algorithmic_gbs': round(12.0 * postings / (ms_b * 1e-3) / 1e9, 1),
+                     'bound': 'instruction issue (the postings are L2 hits in tile-major order: the algorithmic rate is no HBM rate)',
+                     'sq_counters': issue},
+            'fuse_us_per_query': round(ms_f * 1e3 / args.batch, 3)}
+        del s3
         sweep = []
         for bsz in (1, 32, 256):
             sub = argparse.Namespace(**{**vars(args), 'batch': bsz})

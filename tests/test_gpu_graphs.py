@@ -128,6 +128,44 @@ def test_graphed_rerank_with_empty_trailing_slots_on_a_full_token_grid(monkeypat
     rag_hip.check_faults()
 
 
+def test_profile_hooks_around_a_graphed_search():
+    """The three measurement hooks record HIP event pairs around their launches; on a capturing stream they must record
+    nothing (an event recorded into a graph cannot be read back).  With every hook switched on, a single query is
+    captured and replayed, the hooks' reads return, and the results equal those with the hooks off."""
+    from indexing.batch import BatchSearcher, TokenStore
+    import rag_hip
+    rag_hip.init(0)
+    dev = torch.device('cuda:0')
+    w = _world(dev)
+    mk = lambda: BatchSearcher(w['dense'], w['bm25'], bi_encoder=w['bi'], cross_encoder=w['ce'],
+                               chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=20)
+    q = _queries(w, 1, 4242, dev)
+    want = mk().search(*q)
+    torch.cuda.synchronize()
+    w['dense'].profile(True)
+    rag_hip.enc_mlp_profile(True)
+    rag_hip.enc_linear_ln_split_profile(True)
+    try:
+        s = mk()
+        outs = [s.search(*q) for _ in range(3)]            # capture (hooks on), then two replays
+        torch.cuda.synchronize()
+        assert any(k[0] == 'rerank' and g is not None for k, g in s._graphs.graphs.items())
+        scan_ms = w['dense'].profile_read()                # eager launches (the dense scan is not in a graph) were timed ...
+        assert len(scan_ms) == 3 and float(scan_ms.min()) > 0
+        ms, rows = rag_hip.enc_mlp_profile_read()          # ... and the reads of the encoder hooks return (no launch of theirs
+        ms2, rows2, k2 = rag_hip.enc_linear_ln_split_profile_read()   # outside a capture, so nothing to report or everything finite)
+        assert np.all(np.isfinite(ms)) and np.all(np.isfinite(ms2))
+    finally:
+        w['dense'].profile(False)
+        rag_hip.enc_mlp_profile(False)
+        rag_hip.enc_linear_ln_split_profile(False)
+    for o in outs:
+        assert torch.equal(o['rows'], want['rows']) and float((o['logits'] - want['logits']).abs().max()) < 2e-6
+    rag_hip.check_faults()
+    w['dense'].close()
+    w['bm25'].close()
+
+
 def test_the_graph_cache_is_bounded(monkeypatch):
     """A serving loop with varied shapes must not keep one captured forward (and its memory pool) per shape for ever."""
     from indexing.bert import GraphCache
