@@ -103,7 +103,7 @@ class BatchSearcher:
         # weights in float16, one matrix-core product per product) that scores every pair; only the pairs whose cheap
         # logit lies within a margin of their query's cheap k-th best are scored by `cross_encoder`, and the final order
         # and rerank_score come from those exact logits alone.
-        self.screen_encoder = screen_encoder if (screen_encoder is not None and self.ce_packed) else None
+        self.screen_encoder = screen_encoder if cross_encoder is not None else None
         self.screen_safety, self.screen_min_pairs = float(screen_safety), int(screen_min_pairs)
         self.screen_min_safety = min(float(screen_min_safety), self.screen_safety)
         self._screen_err = None                      # running estimate of the screen's error (None: the next batch rescores every pair)

@@ -71,8 +71,16 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
     if device != 'cpu':
         rag_hip.init(0)
     dv = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(device)
-    s = BatchSearcher(dense, bm25, canon=dv(w['canon']), bi_encoder=bi,
-                      cross_encoder=ce if reranker == 'cross' else None, simple_rerank=reranker == 'simple',
+    screen = None
+    if reranker == 'cross-screened':
+        # the screen-then-rescore rerank: the cheap model is the cross-encoder with its weights rounded to float16
+        import copy
+        screen = copy.deepcopy(ce)
+        with torch.no_grad():
+            for p in screen.parameters():
+                p.copy_(p.half().float())
+    s = BatchSearcher(dense, bm25, canon=dv(w['canon']), bi_encoder=bi, screen_encoder=screen, screen_min_pairs=1,
+                      cross_encoder=ce if reranker.startswith('cross') else None, simple_rerank=reranker == 'simple',
                       chunk_tokens=TokenStore(dv(w['tok']), dv(w['off'])),
                       top_k=4, rerank_top_n=11, fusion_method=fusion, vector_weight=0.6, bm25_weight=0.4,
                       ce_pairs_per_batch=16, dist=dist)
@@ -95,6 +103,12 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
                     assert torch.allclose(v, again[k], atol=1e-5), k
                 else:
                     assert torch.equal(v, again[k]), k
+    if screen is not None:
+        # a third search: the first had no error estimate (every pair rescored), later ones screen for real
+        third = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]), ce_tok, ce_off)
+        assert s.screen_stats['batches'] >= 2 and s.last_rescored is not None
+        assert torch.equal(third['rows'], out['rows']), 'the screened rerank changed the final rows'
+        out = dict(third, rescored_fraction=torch.tensor(s.screen_stats['rescored'] / max(s.screen_stats['pairs'], 1)))
     if rank == 0:
         torch.save({k: v.cpu() for k, v in out.items() if torch.is_tensor(v)}, out_path)
     if dist is not None:

@@ -61,6 +61,18 @@ def test_two_shards_equal_one_with_the_simple_reranker(tmp_path):
     assert torch.equal(one['rerank_score'], two['rerank_score'])          # the same float32 dot products
 
 
+def test_two_shards_with_the_screened_rerank_equal_one_without(tmp_path):
+    """Screen-then-rescore across ranks: the cheap logits are gathered, every rank takes the same decisions, the chosen
+    pairs are split across the ranks and their exact logits gathered.  Same final rows and scores as one rank that
+    scores every pair exactly."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'cosine', 'cross')
+    two = _run(2, str(tmp_path / 'two.pt'), 'rrf', 'cosine', 'cross-screened')
+    assert torch.equal(one['fused_row'], two['fused_row']) and torch.equal(one['fused_score'], two['fused_score'])
+    assert torch.equal(one['rows'], two['rows']) and torch.equal(one['count'], two['count'])
+    assert torch.allclose(one['rerank_score'], two['rerank_score'], atol=1e-5)
+    assert 0.0 < float(two['rescored_fraction']) <= 1.0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('reranker', ['cross', 'simple'])
 def test_two_ranks_on_one_gpu_equal_one_with_the_real_kernels(tmp_path, reranker):
