@@ -72,6 +72,7 @@ class VectorIndexer:
         self._canon = None
         self._code_cols, self._row_filter = {}, None   # per-key categorical codes for device-side filters
         self._text_rows = None              # text -> first row holding it (rows_of_texts)
+        self.rows_are_embeddings = False    # the rows are this embedder's embeddings of the payload texts (index_chunks)
         self._created = False
 
     # ---- store management ------------------------------------------------------------
@@ -121,6 +122,9 @@ class VectorIndexer:
         self._canon = np.fromfile(d / 'canon.u32', dtype=np.uint32)
         self.distance_metric = meta.get('distance_metric', self.distance_metric)
         self._index = rag_hip.DenseIndex(rows, metric=self.distance_metric)
+        # rows count as "this embedder's embedding of the payload text" only if index_chunks wrote them with this model
+        self.rows_are_embeddings = bool(meta.get('rows_are_embeddings')) and \
+            meta.get('model_name') == getattr(self.embedder, 'model_name', None)
         return True
 
     # ---- build -----------------------------------------------------------------------
@@ -140,10 +144,13 @@ class VectorIndexer:
                 'text': d.get('text', ''),
                 'metadata': d.get('metadata', {}),
             })
-        self.add_points(emb, payloads)
+        self.add_points(emb, payloads, _embedded_here=True)
 
-    def add_points(self, vectors: np.ndarray, payloads: List[Dict]):
-        """Store precomputed vectors (replaces the collection's content)."""
+    def add_points(self, vectors: np.ndarray, payloads: List[Dict], _embedded_here: bool = False):
+        """Store precomputed vectors (replaces the collection's content).  Vectors handed in from outside are not
+        known to be this embedder's embeddings of the payload texts: only index_chunks marks the rows as such
+        (`rows_are_embeddings`, which the simple reranker's resident-row route requires)."""
+        self.rows_are_embeddings = bool(_embedded_here)
         rows = np.ascontiguousarray(vectors, dtype=np.float32)
         if rows.ndim != 2 or rows.shape[0] != len(payloads):
             raise ValueError("need one vector per payload")
@@ -166,7 +173,8 @@ class VectorIndexer:
             with open(d / 'meta.json', 'w', encoding='utf-8') as f:
                 json.dump({'format': 'rag_hip.dense.v1', 'points_count': int(rows.shape[0]),
                            'embedding_dim': int(rows.shape[1]), 'distance_metric': self.distance_metric,
-                           'model_name': self.embedder.model_name}, f, indent=2)
+                           'model_name': self.embedder.model_name,
+                           'rows_are_embeddings': self.rows_are_embeddings}, f, indent=2)
 
     # ---- search ----------------------------------------------------------------------
     def row_mask(self, filters: Dict):

@@ -91,6 +91,11 @@ class SimpleSimilarityReranker(BaseReranker):
     def _score_from_rows(self, pairs):
         vi = self.vector_indexer
         texts = [t for _, t in pairs]
+        vi._attach()
+        if not getattr(vi, 'rows_are_embeddings', False):
+            # the collection's vectors came from outside (add_points) or from another model: they are not known to be
+            # this embedder's embeddings of the texts, and the reference's score is cosine(encode(q), encode(text))
+            return self._score_by_embedding(pairs[0][0], texts)
         rows = vi.rows_of_texts(texts)
         out = [0.0] * len(pairs)
         held = [i for i, r in enumerate(rows) if r >= 0]

@@ -399,6 +399,17 @@ def test_simple_reranker_from_resident_rows_equals_re_embedding(backend):
     assert np.allclose(a, b, atol=2e-6)
     ra, rb = plain.rerank(q, copy.deepcopy(results), top_k=10), fast.rerank(q, copy.deepcopy(results), top_k=10)
     assert [r['chunk_id'] for r in ra] == [r['chunk_id'] for r in rb]
+    # vectors handed in from outside are not known to be this embedder's embeddings of the texts: the reranker then
+    # embeds the texts itself, as the reference does (rerank.py:60-68), instead of scoring from the stored rows
+    assert vi.rows_are_embeddings
+    foreign = VectorIndexer('f', e, use_in_memory=True)
+    foreign.create_collection()
+    rng = np.random.default_rng(0)
+    foreign.add_points(rng.standard_normal((len(chunks), e.embedding_dim)).astype(np.float32),
+                       [dict(c, chunk_id=c['chunk_id']) for c in chunks])
+    assert not foreign.rows_are_embeddings
+    c = SimpleSimilarityReranker(embedder=e, top_n=30, vector_indexer=foreign).score_pairs(pairs)
+    assert np.allclose(a, c, atol=2e-6)               # the reference's cosines, not dot products with the random rows
     # a collection of another metric or embedder is not used
     other = VectorIndexer('d', e, use_in_memory=True, distance_metric='dot')
     assert build_reranker('simple', embedder=e, vector_indexer=other).vector_indexer is None
