@@ -32,19 +32,36 @@ struct FuseParams {
 // val[e]: the entry's contribution.  Python's dict semantics, restated per unique id:
 //   total(id) = ((0 + val[e1]) + val[e2]) + ...   over its entries in list order,
 //   ids ordered by first appearance; output = stable sort of the ids by total, descending.
-template <bool WEIGHTED>
-__global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
-    __shared__ uint32_t ids_s[FUSE_WAVES][FUSE_MAX];
-    __shared__ double val_s[FUSE_WAVES][FUSE_MAX];
-    __shared__ double tot_s[FUSE_WAVES][FUSE_MAX];   // total of the id, at its first entry; NaN-free marker below
-    __shared__ uint8_t lead_s[FUSE_WAVES][FUSE_MAX];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int q = blockIdx.x * FUSE_WAVES + w;
+// TEAM = waves that share one query.  Large batches run one wave per query (FUSE_WAVES queries per workgroup: a
+// thousand queries fill the chip); for a handful of queries the three quadratic passes of a single wave are the
+// latency of the whole stage (153 us for one query with two lists of 100), so a workgroup of four waves takes one
+// query, a thread an entry: every thread still sums its own id's entries in list order, so the totals are the same bits.
+template <bool WEIGHTED, int TEAM>
+__global__ __launch_bounds__(FUSE_WAVES * 64 > TEAM * 64 ? FUSE_WAVES * 64 : TEAM * 64) void fuse_kernel(FuseParams p) {
+    constexpr int SLOTS = TEAM == 1 ? FUSE_WAVES : 1;      // queries per workgroup
+    constexpr int NT = 64 * TEAM;                          // threads per query
+    __shared__ uint32_t ids_s[SLOTS][FUSE_MAX];
+    __shared__ double val_s[SLOTS][FUSE_MAX];
+    __shared__ double tot_s[SLOTS][FUSE_MAX];   // total of the id, at its first entry; NaN-free marker below
+    __shared__ uint8_t lead_s[SLOTS][FUSE_MAX];
+    __shared__ double red_s[4][TEAM];
+    __shared__ int cnt_s[TEAM];
+    const int lane = threadIdx.x % NT, w = threadIdx.x / NT, wave = (threadIdx.x >> 6) % TEAM;
+    const int q = blockIdx.x * SLOTS + w;
     if (q >= p.n_queries) return;
     uint32_t* ids = ids_s[w];
     double* val = val_s[w];
     double* tot = tot_s[w];
     uint8_t* lead = lead_s[w];
+    auto team_sync = [&]() {
+        if constexpr (TEAM == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __syncthreads();
+        }
+    };
 
     const int nv = min(p.vec_count ? p.vec_count[q] : 0, p.vec_stride);
     const int nb = min(p.bm_count ? p.bm_count[q] : 0, p.bm_stride);
@@ -55,19 +72,25 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
     double vmin = 0, vmax = 0, bmin = 0, bmax = 0;
     if (WEIGHTED) {
         // per-list min / max (exact, order free)
-        double lo = INFINITY, hi = -INFINITY;
-        for (int e = lane; e < nv; e += 64) { double s = (double)p.vec_score[(size_t)q * p.vec_stride + e]; lo = fmin(lo, s); hi = fmax(hi, s); }
+        double lo = INFINITY, hi = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+        for (int e = lane; e < nv; e += NT) { double s = (double)p.vec_score[(size_t)q * p.vec_stride + e]; lo = fmin(lo, s); hi = fmax(hi, s); }
+        for (int e = lane; e < nb; e += NT) { double s = p.bm_score[(size_t)q * p.bm_stride + e]; lo2 = fmin(lo2, s); hi2 = fmax(hi2, s); }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
-        vmin = lo; vmax = hi;
-        lo = INFINITY; hi = -INFINITY;
-        for (int e = lane; e < nb; e += 64) { double s = p.bm_score[(size_t)q * p.bm_stride + e]; lo = fmin(lo, s); hi = fmax(hi, s); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
-        bmin = lo; bmax = hi;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64));
+            lo2 = fmin(lo2, __shfl_xor(lo2, off, 64)); hi2 = fmax(hi2, __shfl_xor(hi2, off, 64));
+        }
+        if constexpr (TEAM > 1) {
+            if ((threadIdx.x & 63) == 0) { red_s[0][wave] = lo; red_s[1][wave] = hi; red_s[2][wave] = lo2; red_s[3][wave] = hi2; }
+            __syncthreads();
+            for (int t = 0; t < TEAM; ++t) {
+                lo = fmin(lo, red_s[0][t]); hi = fmax(hi, red_s[1][t]); lo2 = fmin(lo2, red_s[2][t]); hi2 = fmax(hi2, red_s[3][t]);
+            }
+        }
+        vmin = lo; vmax = hi; bmin = lo2; bmax = hi2;
     }
 
-    for (int e = lane; e < n; e += 64) {
+    for (int e = lane; e < n; e += NT) {
         const bool is_vec = e < nv;
         const int64_t row = is_vec ? vrow[e] : brow[e - nv];
         uint32_t id = (uint32_t)row;
@@ -91,39 +114,42 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
         }
         val[e] = c;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    team_sync();
 
     // first appearance + in-order totals
-    for (int e = lane; e < n; e += 64) {
+    int mine = 0;
+    for (int e = lane; e < n; e += NT) {
         const uint32_t id = ids[e];
         bool first = true;
         for (int j = 0; j < e; ++j) if (ids[j] == id) { first = false; break; }
         lead[e] = first ? 1 : 0;
+        mine += first ? 1 : 0;
         if (first) {
             double t = val[e];                      // 0 + x == x
             for (int j = e + 1; j < n; ++j) if (ids[j] == id) t = __dadd_rn(t, val[j]);
             tot[e] = t;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
     // rank among the unique ids: better total first, ties by first appearance
-    int n_unique = 0;
-    for (int e = lane; e < n; e += 64) n_unique += lead[e];
+    int n_unique = mine;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_unique += __shfl_xor(n_unique, off, 64);
+    if constexpr (TEAM > 1) {
+        if ((threadIdx.x & 63) == 0) cnt_s[wave] = n_unique;
+    }
+    team_sync();
+    if constexpr (TEAM > 1) {
+        n_unique = 0;
+        for (int t = 0; t < TEAM; ++t) n_unique += cnt_s[t];
+    }
     const int n_out = min(n_unique, p.top_k);
     int32_t* opos = p.out_pos + (size_t)q * p.top_k;
     int64_t* orow = p.out_row + (size_t)q * p.top_k;
     double* osc = p.out_score + (size_t)q * p.top_k;
-    for (int i = n_out + lane; i < p.top_k; i += 64) { opos[i] = -1; orow[i] = -1; osc[i] = 0.0; }
+    for (int i = n_out + lane; i < p.top_k; i += NT) { opos[i] = -1; orow[i] = -1; osc[i] = 0.0; }
     if (lane == 0) p.out_count[q] = n_out;
 
-    for (int e = lane; e < n; e += 64) {
+    for (int e = lane; e < n; e += NT) {
         if (!lead[e]) continue;
         const double t = tot[e];
         int rank = 0;
@@ -146,6 +172,17 @@ __global__ __launch_bounds__(FUSE_WAVES * 64) void fuse_kernel(FuseParams p) {
             osc[rank] = t;
         }
     }
+}
+
+constexpr int FUSE_TEAM = 4;                       // waves per query of the small-batch form
+constexpr int FUSE_TEAM_MAX_QUERIES = 128;         // ... used up to this many queries
+
+template <bool WEIGHTED>
+void launch_fuse(const FuseParams& p, int n_queries, hipStream_t stream) {
+    if (n_queries <= FUSE_TEAM_MAX_QUERIES)
+        fuse_kernel<WEIGHTED, FUSE_TEAM><<<n_queries, FUSE_TEAM * 64, 0, stream>>>(p);
+    else
+        fuse_kernel<WEIGHTED, 1><<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, stream>>>(p);
 }
 
 // Stable descending order of each pool's scores, cut at top_k: one wave per pool.
@@ -339,7 +376,7 @@ extern "C" int rag_fuse_rrf_dev(const int64_t* d_vec_row, const int32_t* d_vec_c
     p.canon = n_canon > 0 ? d_canon : nullptr; p.n_canon = n_canon; p.fault = rag_fault_word();
     p.n_queries = n_queries; p.top_k = top_k; p.k_const = k_const;
     p.out_pos = d_out_pos; p.out_row = d_out_row; p.out_score = d_out_score; p.out_count = d_out_count;
-    fuse_kernel<false><<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, (hipStream_t)stream>>>(p);
+    launch_fuse<false>(p, n_queries, (hipStream_t)stream);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -364,7 +401,7 @@ extern "C" int rag_fuse_weighted_dev(const int64_t* d_vec_row, const double* d_v
     p.canon = n_canon > 0 ? d_canon : nullptr; p.n_canon = n_canon; p.fault = rag_fault_word();
     p.n_queries = n_queries; p.top_k = top_k; p.vw = vector_weight; p.bw = bm25_weight;
     p.out_pos = d_out_pos; p.out_row = d_out_row; p.out_score = d_out_score; p.out_count = d_out_count;
-    fuse_kernel<true><<<(n_queries + FUSE_WAVES - 1) / FUSE_WAVES, FUSE_WAVES * 64, 0, (hipStream_t)stream>>>(p);
+    launch_fuse<true>(p, n_queries, (hipStream_t)stream);
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

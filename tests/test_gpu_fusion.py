@@ -70,15 +70,16 @@ def test_weighted_matches_reference_fixture(name):
         assert payload == e
 
 
-@pytest.mark.parametrize('seed', range(4))
-def test_fusion_random_batches_match_oracle(seed):
+@pytest.mark.parametrize('seed,B', [(0, 37), (1, 37), (2, 1), (3, 128), (4, 129), (5, 300)])
+def test_fusion_random_batches_match_oracle(seed, B):
+    """(up to 128 queries a workgroup of four waves fuses one query, beyond that a wave: both forms, both sides of the switch)"""
     import rag_hip
     rng = np.random.default_rng(seed)
     n_rows = 5000
     canon = np.arange(n_rows, dtype=np.uint32)
     for d in np.sort(rng.choice(np.arange(1, n_rows), 400, replace=False)):
         canon[d] = canon[int(rng.integers(0, d))]              # an earlier row's canonical row
-    B, T = 37, int(rng.integers(1, 60))
+    T = int(rng.integers(1, 60))
     v_rows, b_rows, v_sc, b_sc = [], [], [], []
     for q in range(B):
         nv, nb = int(rng.integers(0, 2 * T + 1)), int(rng.integers(0, 2 * T + 1))
