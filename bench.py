@@ -81,6 +81,10 @@ def parse():
                     help='run the embedder GEMMs as fp32 GEMMs instead of split-bf16 products with fp32 accumulation')
     ap.add_argument('--ce-fused-attn-out', action='store_true',
                     help='tuning aid: attention-output projection + LayerNorm inside the feed-forward kernel')
+    ap.add_argument('--ce-fused-norm-mlp', action='store_true',
+                    help='tuning aid: residual + LayerNorm after the output projection inside the feed-forward kernel '
+                         '(the default of the float16 screening forward)')
+    ap.add_argument('--ce-no-fused-norm-mlp', action='store_true', help='tuning aid: ... and as a pass of its own there too')
     ap.add_argument('--ce-fused-attn-norm', action='store_true',
                     help='tuning aid: residual + LayerNorm after the output projection inside rag_enc_linear384_dev')
     ap.add_argument('--pipeline', action='store_true',
@@ -373,6 +377,7 @@ def main():
         m.bert.native_linear = not args.ce_library_linear
         m.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
         m.bert.fused_tail = bool(args.ce_fused_attn_out)
+        m.bert.fused_norm_mlp = bool(args.ce_fused_norm_mlp) or (kind == 'fp16' and not args.ce_no_fused_norm_mlp)
         return m
 
     def make_searcher(model, top_n, with_dist=True, screen=None):

@@ -781,7 +781,7 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
                                         const void* d_w2, const void* d_b2, const void* d_gamma2, const void* d_beta2,
                                         float eps, int64_t m, int32_t hidden, int32_t intermediate, int32_t dtype,
                                         void* d_y, void* stream_) {
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_attn_out_mlp: bf16 only");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_attn_out_mlp: bf16 or fp16 only");
     RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_attn_out_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
     RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
                 "rag_enc_attn_out_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I,
@@ -792,17 +792,21 @@ extern "C" int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, cons
                 RAG_EINVAL, "rag_enc_attn_out_mlp: null pointer");
     RAG_REQUIRE(aligned16({d_ctx, d_x, d_wo, d_bo, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
                 "rag_enc_attn_out_mlp: pointers must be 16-byte aligned");
-    MlpParamsT<bf16> p = mlp_params<bf16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
-    p.ctx = (const bf16*)d_ctx; p.wo = (const bf16*)d_wo; p.bo = (const bf16*)d_bo;
-    p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
-    return launch_mlp(p, 1, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
+    auto run = [&](auto elem) -> int {
+        using E = decltype(elem);
+        MlpParamsT<E> p = mlp_params<E>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
+        p.ctx = (const E*)d_ctx; p.wo = (const E*)d_wo; p.bo = (const E*)d_bo;
+        p.gamma1 = (const E*)d_gamma1; p.beta1 = (const E*)d_beta1;
+        return launch_mlp(p, 1, (hipStream_t)stream_, "rag_enc_attn_out_mlp");
+    };
+    return dtype == RAG_DTYPE_F16 ? run(f16{}) : run(bf16{});
 }
 
 extern "C" int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const void* d_gamma1, const void* d_beta1,
                                     const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                                     const void* d_gamma2, const void* d_beta2, float eps, int64_t m, int32_t hidden,
                                     int32_t intermediate, int32_t dtype, void* d_y, void* stream_) {
-    RAG_REQUIRE(dtype == RAG_DTYPE_BF16, RAG_ELIMIT, "rag_enc_norm_mlp: bf16 only");
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_norm_mlp: bf16 or fp16 only");
     RAG_REQUIRE(hidden == ML_HID, RAG_ELIMIT, "rag_enc_norm_mlp: hidden size must be %d (got %d)", ML_HID, hidden);
     RAG_REQUIRE(intermediate >= ML_C && intermediate % ML_C == 0 && intermediate <= ML_MAX_I, RAG_ELIMIT,
                 "rag_enc_norm_mlp: intermediate size must be a multiple of %d up to %d (got %d)", ML_C, ML_MAX_I,
@@ -813,9 +817,13 @@ extern "C" int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const v
                 RAG_EINVAL, "rag_enc_norm_mlp: null pointer");
     RAG_REQUIRE(aligned16({d_proj, d_x, d_gamma1, d_beta1, d_w1, d_w2, d_b2, d_gamma2, d_beta2, d_y}), RAG_EINVAL,
                 "rag_enc_norm_mlp: pointers must be 16-byte aligned");
-    MlpParamsT<bf16> p = mlp_params<bf16>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
-    p.ctx = (const bf16*)d_proj; p.gamma1 = (const bf16*)d_gamma1; p.beta1 = (const bf16*)d_beta1;
-    return launch_mlp(p, 2, (hipStream_t)stream_, "rag_enc_norm_mlp");
+    auto run = [&](auto elem) -> int {
+        using E = decltype(elem);
+        MlpParamsT<E> p = mlp_params<E>(d_x, d_w1, d_b1, d_w2, d_b2, d_gamma2, d_beta2, d_y, m, intermediate, eps);
+        p.ctx = (const E*)d_proj; p.gamma1 = (const E*)d_gamma1; p.beta1 = (const E*)d_beta1;
+        return launch_mlp(p, 2, (hipStream_t)stream_, "rag_enc_norm_mlp");
+    };
+    return dtype == RAG_DTYPE_F16 ? run(f16{}) : run(bf16{});
 }
 
 extern "C" int rag_enc_mlp_profile(int32_t enable) {

@@ -228,7 +228,7 @@ class BertEncoder(nn.Module):
         import rag_hip
         return (self.fused_mlp and self.fused_tail and l.attn_norm.eps == l.ffn_norm.eps
                 and rag_hip.enc_mlp_supported(x, l.ffn_in.weight, l.ffn_out.weight)
-                and l.attn_out.weight.dtype == torch.bfloat16)     # (the fused tail kernels are bfloat16 only)
+                and l.attn_out.weight.dtype in (torch.bfloat16, torch.float16))
 
     def _norm_mlp_fused(self, l, x, ctx):
         import rag_hip
@@ -672,6 +672,9 @@ def load_model(spec, kind, device, dtype=torch.float32, seed=0, native=False, sp
         native = (torch.device(device).type == 'cuda' and dtype in (torch.bfloat16, torch.float16, torch.float32)
                   and cfg.hidden_size // cfg.num_attention_heads in (32, 64))
     model.bert.native = bool(native)
+    # float16 weights (the screening forward of the batched rerank): residual + LayerNorm behind the output projection
+    # inside the feed-forward kernel (one pass and one rounding fewer: 155.1 against 156.8 ms of rerank per 1024 queries)
+    model.bert.fused_norm_mlp = dtype == torch.float16
     model.bert.split_gemm = bool(split_gemm)
     if split_dtype is not None:
         model.bert.split_dtype = split_dtype

@@ -1060,10 +1060,12 @@ def enc_attn_out_mlp_dev(ctx, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, 
         if tuple(v.shape) != (hid,):
             raise ValueError("bo, b2 and the LayerNorm vectors must be [H]")
     y = torch.empty_like(x)
-    bf = torch.bfloat16
+    bf = x.dtype
+    if not _is_16bit(bf):
+        raise ValueError("enc_attn_out_mlp_dev handles bfloat16 and float16")
     check(lib().rag_enc_attn_out_mlp_dev(_ptr(ctx, bf), _ptr(x, bf), _ptr(wo, bf), _ptr(bo, bf), _ptr(gamma1, bf),
                                          _ptr(beta1, bf), _ptr(w1, bf), _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf),
-                                         _ptr(gamma2, bf), _ptr(beta2, bf), float(eps), m, hid, inter, DTYPE_BF16,
+                                         _ptr(gamma2, bf), _ptr(beta2, bf), float(eps), m, hid, inter, _enc_dtype(x),
                                          _ptr(y), _stream()), 'rag_enc_attn_out_mlp_dev')
     return y
 
@@ -1082,10 +1084,12 @@ def enc_norm_mlp_dev(proj, x, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps=
         if tuple(v.shape) != (hid,):
             raise ValueError("b2 and the LayerNorm vectors must be [H]")
     y = torch.empty_like(x)
-    bf = torch.bfloat16
+    bf = x.dtype
+    if not _is_16bit(bf):
+        raise ValueError("enc_norm_mlp_dev handles bfloat16 and float16")
     check(lib().rag_enc_norm_mlp_dev(_ptr(proj, bf), _ptr(x, bf), _ptr(gamma1, bf), _ptr(beta1, bf), _ptr(w1, bf),
                                      _ptr(b1, bf), _ptr(w2, bf), _ptr(b2, bf), _ptr(gamma2, bf), _ptr(beta2, bf),
-                                     float(eps), m, hid, inter, DTYPE_BF16, _ptr(y), _stream()), 'rag_enc_norm_mlp_dev')
+                                     float(eps), m, hid, inter, _enc_dtype(x), _ptr(y), _stream()), 'rag_enc_norm_mlp_dev')
     return y
 
 
