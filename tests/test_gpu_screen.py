@@ -134,3 +134,43 @@ def test_small_batches_take_the_exact_path_only():
     assert s.last_rescored is None and s.screen_stats['batches'] == 0
     w['dense'].close()
     w['bm25'].close()
+
+
+def test_screened_rerank_with_ragged_and_empty_pools():
+    """Pools shorter than rerank_top_n, shorter than top_k, and empty (fused rows -1 behind the count): the screen must
+    rescore whole pools that cannot fill a top k, never choose an empty slot, and agree with the exact rerank."""
+    from indexing.batch import BatchSearcher, TokenStore
+    import rag_hip
+    dev = torch.device('cuda:0')
+    w = _world(dev, 'hf-default', n=8000)
+    b, t = 320, 24
+    rng = np.random.default_rng(91)
+    cnt = rng.integers(0, t + 1, size=b)
+    cnt[:6] = [0, 1, 4, 5, 6, t]
+    rows = np.full((b, t), -1, np.int64)
+    for i in range(b):
+        rows[i, :cnt[i]] = rng.choice(8000, size=cnt[i], replace=False)
+    fused_row = torch.from_numpy(rows).to(dev)
+    fused_cnt = torch.from_numpy(cnt.astype(np.int32)).to(dev)
+    _, _, _, ce_tok, ce_off = _queries(w, b, 33, dev)
+    mk = lambda screen: BatchSearcher(w['dense'], w['bm25'], cross_encoder=w['exact'], screen_encoder=screen,
+                                      chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=t)
+    plain, screened = mk(None), mk(w['cheap'])
+    for it in range(2):                                   # the second call is the screened one
+        iw, cw, lw = plain.rerank(ce_tok, ce_off, fused_row, fused_cnt)
+        ig, cg, lg = screened.rerank(ce_tok, ce_off, fused_row, fused_cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(cg, cw) and torch.equal(cg.cpu(), torch.clamp(fused_cnt.cpu(), max=5))
+        live = torch.arange(t, device=dev)[None, :] < fused_cnt[:, None]
+        srt = torch.sort(torch.where(live, lw, torch.full_like(lw, -1e30)).double(), dim=1, descending=True).values
+        gap = (srt[:, :5] - srt[:, 1:6]).abs().min(dim=1).values
+        same = (ig == iw).all(dim=1)
+        assert bool((same | (gap < 4e-6)).all())
+        mask = screened.last_rescored
+        assert bool((mask <= live).all())                 # no empty slot was scored as a pair
+        short = fused_cnt <= 5
+        assert bool((mask[short] == live[short]).all())   # pools that cannot fill a top 5 are rescored whole
+    assert screened.screen_stats['rescored'] < screened.screen_stats['pairs']
+    rag_hip.check_faults()
+    w['dense'].close()
+    w['bm25'].close()
