@@ -78,11 +78,16 @@ constexpr int ML_YT = ML_HID / 32;           // accumulator tiles of Y^T: 12
 constexpr int ML_W_BYTES = ML_C * ML_HID * 2;             // one W1 chunk = one W2 chunk = 24576 B
 constexpr int ML_W_DMAS = ML_W_BYTES / 1024 / (ML_NT / 64);   // 1-KiB direct-to-LDS loads per wave and chunk: 6
 constexpr int ML_PF = 3;                    // fragment reads run this many k-steps ahead of their MFMAs
-constexpr int ML_MAX_I = 8192;               // b1 sits in LDS
-// LDS image: W1 buffers [2][32 rows][48 x 16 B], W2 buffers [2][384 rows][4 x 16 B], b1 [I] as fp32,
+constexpr int ML_MAX_I = 2048;               // b1 sits in LDS (beside three W1 and three W2 buffers: 160 KB in all)
+// LDS image: W1 buffers [3][32 rows][48 x 16 B], W2 buffers [3][384 rows][4 x 16 B] (rings of three: a chunk's weights
+// are asked for two iterations before they are used), b1 [I] as fp32,
 // then b2, gamma, beta [384] as bf16
-constexpr int ML_OFF_W2 = 2 * ML_W_BYTES;
-constexpr int ML_OFF_B1 = 4 * ML_W_BYTES;
+#ifndef ML_DMA_EVERY
+#define ML_DMA_EVERY 2      // one weight piece every this many k-steps (12 pieces per wave and chunk over 24 steps)
+#endif
+constexpr int ML_RING = 3;
+constexpr int ML_OFF_W2 = ML_RING * ML_W_BYTES;
+constexpr int ML_OFF_B1 = 2 * ML_RING * ML_W_BYTES;
 
 template <typename E>
 struct MlpParamsT {
@@ -226,7 +231,11 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
     const int last = n_chunks - 1;
     dma_w1(0, 0);
     dma_w1(min(1, last), 1);
-    if constexpr (!PROJ) dma_w2(0, 0);   // PROJ: the W2 buffers carry Wo first
+    dma_w1(min(2, last), 2);
+    if constexpr (!PROJ) {               // PROJ: the W2 buffers carry Wo first
+        dma_w2(0, 0);
+        dma_w2(min(1, last), 1);
+    }
     for (int i = tid; i < p.I; i += ML_NT) *reinterpret_cast<float*>(smem + ML_OFF_B1 + 4 * i) = (float)p.b1[i];
     for (int i = tid; i < (PRE_LN ? 6 : 3) * (ML_HID / 8); i += ML_NT) {   // b2 | gamma | beta | bo | gamma1 | beta1 behind b1, 16-bit
         const int vsel = i / (ML_HID / 8), piece = i % (ML_HID / 8);
@@ -259,6 +268,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
                             (uint32_t)(uintptr_t)a1[3], (uint32_t)(uintptr_t)a1[4], (uint32_t)(uintptr_t)a1[5],
                             (uint32_t)(uintptr_t)a1[6], (uint32_t)(uintptr_t)a1[7]};
     const uint32_t l2[2] = {(uint32_t)(uintptr_t)a2[0], (uint32_t)(uintptr_t)a2[1]};
+    // (a read's immediate offset has 16 bits: the third ring slot of the W2 images lies beyond them)
+    const uint32_t l2c[2] = {l2[0] + 2 * ML_W_BYTES, l2[1] + 2 * ML_W_BYTES};
     const uint32_t lb = (uint32_t)(uintptr_t)b1s;
 
     auto gemm1 = [&](int buf, f32x16& acc) {                  // prologue only: compiler-scheduled reads
@@ -325,7 +336,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
             __syncthreads();
         };
         unrolled(std::make_integer_sequence<int, ML_HID / ML_C>{}, slice);
-        dma_w2(0, 0);                                         // both W2 buffers are free again
+        dma_w2(0, 0);                                         // the W2 buffers are free again
+        dma_w2(min(1, last), 1);
       }
         // bias, residual, LayerNorm; the result replaces the ctx fragments in xf
         // (MODE 2: the accumulator registers only serve as the fp32 copy of the row)
@@ -368,36 +380,41 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- prologue: H^T of chunks 0 and 1; then W1 buffer 0 is free for chunk 2
+    // ---- prologue: H^T of chunks 0 and 1; then W1 buffer 0 is free for chunk 3
     f32x16 hA, hB;
     e8 pA[2], pB[2];
     gemm1(0, hA);
     gemm1(1, hB);
     __syncthreads();
-    dma_w1(min(2, last), 0);
+    dma_w1(min(3, last), 0);
     gelu_pack(0, hA, pA);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---- main loop, three chunks in flight: iteration c runs H^T of chunk c+2 (into hnew), the GELU
     // of chunk c+1 (hold -> pnext) and Y^T += W2 . H^T of chunk c (pcur) — independent of one another,
-    // so the matrix unit, the vector ALU and the LDS reads overlap — while chunks c+3 of W1 and c+1 of
-    // W2 stream into the buffers the previous iteration finished with.  Past the last chunk the loads
-    // and the first product repeat the last chunk (results unused): no branches in the body.  Two
-    // iterations are written out with the roles of the accumulators swapped and the buffer index a
-    // constant, so every fragment address is a fixed register plus an immediate.
+    // so the matrix unit, the vector ALU and the LDS reads overlap — while chunks c+4 of W1 and c+2 of
+    // W2 stream into the ring slots the previous iteration finished with.  The weights an iteration asks
+    // for are used by the iteration after the next: the wait that closes an iteration leaves its own loads
+    // in flight (counted vmcnt) and only makes sure of the previous iteration's, so a chunk's 48 KiB have a
+    // whole iteration to pass the CU's address path instead of the half iteration left behind their issue
+    // (waves were parked at that wait 28 % of their life).  Past the last chunk the loads and the first
+    // product repeat the last chunk (results unused): no branches in the body.  Six iterations are written
+    // out — ring slot (three) x roles of the accumulators (two) — with the slot a constant, so every
+    // fragment address is a fixed register plus an immediate.
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if ML_STAMPS
     unsigned long long st[5] = {0, 0, 0, 0, 0};
 #endif
     auto iteration = [&](int c, auto buf_c, f32x16& hnew, const f32x16& hold, const e8* pcur, e8* pnext) {
-        constexpr int BUF = decltype(buf_c)::value;
+        constexpr int R = decltype(buf_c)::value;          // c % 3: W2 chunk c sits in slot R, W1 chunk c + 2 in slot (R + 2) % 3
+        constexpr int RB1 = (R + 2) % ML_RING, WB1 = (R + 1) % ML_RING, WB2 = (R + 2) % ML_RING;
         ML_STAMP(t0);
         // the weight loads are issued one per k-step over the first half of the steps, between MFMAs
         // (issuing one costs the wave some 50 cycles, which the matrix unit covers there and would not
         // cover in one block up front; the second half of the steps gives the last ones time to land)
-        const E* g1 = p.w1 + (size_t)min(c + 3, last) * ML_C * ML_HID;
-        const E* g2 = p.w2 + min(c + 1, last) * ML_C;
+        const E* g1 = p.w1 + (size_t)min(c + 4, last) * ML_C * ML_HID;
+        const E* g2 = p.w2 + min(c + 2, last) * ML_C;
         ML_STAMP(t1);
         // bias of chunk c+1 (for the GELU), then the fragment ring: k-step s uses slot s % (ML_PF + 1)
         f32x4 bias[4];
@@ -410,17 +427,18 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
         f32x2 gv, gc, gs, gp;
         auto issue = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
-            lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q1[S % (ML_PF + 1)], l1[S & 7]);
-            lds_read16<BUF * ML_W_BYTES + (S % ML_YT) * (32 * ML_C * 2)>(q2[S % (ML_PF + 1)], l2[S / ML_YT]);
+            lds_read16<RB1 * ML_W_BYTES + 256 * (S >> 3)>(q1[S % (ML_PF + 1)], l1[S & 7]);
+            if constexpr (R == 2) lds_read16<(S % ML_YT) * (32 * ML_C * 2)>(q2[S % (ML_PF + 1)], l2c[S / ML_YT]);
+            else lds_read16<R * ML_W_BYTES + (S % ML_YT) * (32 * ML_C * 2)>(q2[S % (ML_PF + 1)], l2[S / ML_YT]);
         };
         auto step = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
-            if constexpr (S < 2 * ML_W_DMAS) {
-                constexpr int G = S;
+            if constexpr (S % ML_DMA_EVERY == 0 && S / ML_DMA_EVERY < 2 * ML_W_DMAS) {
+                constexpr int G = S / ML_DMA_EVERY;
                 if constexpr (G < ML_W_DMAS)
-                    lds_dma16(lds0 + (BUF ^ 1) * ML_W_BYTES + 1024 * (wave + 4 * G), g1, off1[G]);
+                    lds_dma16(lds0 + WB1 * ML_W_BYTES + 1024 * (wave + 4 * G), g1, off1[G]);
                 else
-                    lds_dma16(lds0 + ML_OFF_W2 + (BUF ^ 1) * ML_W_BYTES + 1024 * (wave + 4 * (G - ML_W_DMAS)), g2,
+                    lds_dma16(lds0 + ML_OFF_W2 + WB2 * ML_W_BYTES + 1024 * (wave + 4 * (G - ML_W_DMAS)), g2,
                               off2[G - ML_W_DMAS]);
             }
             if constexpr (S + ML_PF < ML_KS) issue(std::integral_constant<int, S + ML_PF>{});
@@ -459,7 +477,8 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]) : "n"(2 * ML_PF));
         unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
         ML_STAMP(t2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this iteration's own 2 * ML_W_DMAS loads may still be in flight; everything older has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ML_W_DMAS) : "memory");
         ML_STAMP(t3);
         __syncthreads();
         ML_STAMP(t4);
@@ -470,10 +489,15 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
 #if ML_STAMPS
     ML_STAMP(tl0);
 #endif
-    for (int c = 0; c < n_chunks; c += 2) {
+    for (int c = 0; c < n_chunks; c += 6) {
         iteration(c, std::integral_constant<int, 0>{}, hA, hB, pA, pB);
         if (c + 1 < n_chunks) iteration(c + 1, std::integral_constant<int, 1>{}, hB, hA, pB, pA);
+        if (c + 2 < n_chunks) iteration(c + 2, std::integral_constant<int, 2>{}, hA, hB, pA, pB);
+        if (c + 3 < n_chunks) iteration(c + 3, std::integral_constant<int, 0>{}, hB, hA, pB, pA);
+        if (c + 4 < n_chunks) iteration(c + 4, std::integral_constant<int, 1>{}, hA, hB, pA, pB);
+        if (c + 5 < n_chunks) iteration(c + 5, std::integral_constant<int, 2>{}, hB, hA, pB, pA);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the repeats of the last chunk: nothing may land in LDS behind this point
 
 #if ML_STAMPS
     ML_STAMP(tl1);
@@ -863,7 +887,7 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
                                      const void* d_residual, const void* d_gamma, const void* d_beta, float eps,
                                      int32_t dtype, void* d_y, void* stream_) {
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_linear384: bf16 or fp16 only");
-    RAG_REQUIRE(n >= ML_C && n % ML_C == 0 && n <= 4 * ML_MAX_I, RAG_ELIMIT,
+    RAG_REQUIRE(n >= ML_C && n % ML_C == 0 && n <= 32768, RAG_ELIMIT,
                 "rag_enc_linear384: the output width must be a multiple of %d (got %d)", ML_C, n);
     RAG_REQUIRE(m >= 0, RAG_EINVAL, "rag_enc_linear384: negative row count");
     if (m == 0) return RAG_OK;

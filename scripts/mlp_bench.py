@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The one-kernel feed-forward block alone (for rocprofv3 --pmc passes and A/B runs).
 
-    python scripts/mlp_bench.py --tokens 1048576 --iters 5
+    python scripts/mlp_bench.py --tokens 1048576 --iters 5 [--dtype fp16] [--only-mlp]
 """
 import argparse
 import os
@@ -19,12 +19,14 @@ def main():
     ap.add_argument('--tokens', type=int, default=1 << 20)
     ap.add_argument('--inter', type=int, default=1536)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'], help='element type of the kernel instance')
+    ap.add_argument('--only-mlp', action='store_true', help='time the feed-forward kernel only (for counter passes)')
     args = ap.parse_args()
     import rag_hip
     dev = torch.device('cuda:0')
     rag_hip.init(0)
     g = torch.Generator(device=dev).manual_seed(1)
-    bf = torch.bfloat16
+    bf = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
     x = torch.randn((args.tokens, 384), generator=g, device=dev).to(bf)
     l1 = torch.nn.Linear(384, args.inter, device=dev, dtype=bf)
     l2 = torch.nn.Linear(args.inter, 384, device=dev, dtype=bf)
@@ -43,6 +45,9 @@ def main():
     fl = 4.0 * args.tokens * 384 * args.inter
     print(f'feed-forward block: tokens={args.tokens} inter={args.inter} {ms:.3f} ms, {fl / ms / 1e9:.0f} TFLOP/s, '
           f'{args.tokens * 384 * 2 * 2 / ms / 1e6:.0f} GB/s algorithmic', flush=True)
+    if args.only_mlp:
+        rag_hip.check_faults()
+        return
     lo = torch.nn.Linear(384, 384, device=dev, dtype=bf)
     ctx = torch.randn((args.tokens, 384), generator=g, device=dev).to(bf)
 
