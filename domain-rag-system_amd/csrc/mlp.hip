@@ -85,6 +85,9 @@ constexpr int ML_MAX_I = 2048;               // b1 sits in LDS (beside three W1 
 #ifndef ML_DMA_EVERY
 #define ML_DMA_EVERY 2      // one weight piece every this many k-steps (12 pieces per wave and chunk over 24 steps)
 #endif
+#ifndef ML_ABLATE_DMA
+#define ML_ABLATE_DMA 0     // timing ablation only (wrong results): the loop without its weight loads
+#endif
 constexpr int ML_RING = 3;
 constexpr int ML_OFF_W2 = ML_RING * ML_W_BYTES;
 constexpr int ML_OFF_B1 = 2 * ML_RING * ML_W_BYTES;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
         };
         auto step = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
-            if constexpr (S % ML_DMA_EVERY == 0 && S / ML_DMA_EVERY < 2 * ML_W_DMAS) {
+            if constexpr (S % ML_DMA_EVERY == 0 && S / ML_DMA_EVERY < 2 * ML_W_DMAS && !ML_ABLATE_DMA) {
                 constexpr int G = S / ML_DMA_EVERY;
                 if constexpr (G < ML_W_DMAS)
                     lds_dma16(lds0 + WB1 * ML_W_BYTES + 1024 * (wave + 4 * G), g1, off1[G]);
