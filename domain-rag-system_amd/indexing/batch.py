@@ -308,14 +308,15 @@ class BatchSearcher:
         logits_mine = torch.zeros((share,), dtype=torch.float32, device=dev)
         if n_mine:
             plen = rag_hip.ce_pair_len_dev(q_off, store.off, store.row_base, my_q, my_r, self.ce_max_len)
+            mine = logits_mine[:n_mine]               # (the last rank's share may be shorter than the padded piece)
             if (self.ce_packed and model is self.cross_encoder and graph_batch
                     and self._graph_ok(graph_batch, dev, self.graph_max_batch_ce)
-                    and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, logits_mine)):
+                    and self._ce_graphed(q_tok, q_off, my_q, my_r, plen, mine)):
                 pass
             elif self.ce_packed:
-                self._ce_packed(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
+                self._ce_packed(model, q_tok, q_off, my_q, my_r, plen, mine)
             else:
-                self._ce_padded(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
+                self._ce_padded(model, q_tok, q_off, my_q, my_r, plen, mine)
         if self.sharded:
             gathered = torch.empty((share * self.world,), dtype=torch.float32, device=dev)
             self._all_gather(gathered, logits_mine)

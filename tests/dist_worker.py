@@ -68,10 +68,17 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
     bm25 = rag_hip.Bm25Index(arr.indptr, arr.rows, arr.impacts(), arr.idf, hi - lo, row_base=lo)
     bi, _, _ = bert.load_model('random:tiny', 'bi', device)
     ce, _, _ = bert.load_model('random:tiny', 'cross', device)
+    native_screen = None
+    if 'native' in reranker:
+        # the packed route of the real kernels: float32-equivalent MiniLM-L6 forward, float16 screening forward
+        ce, _, _ = bert.load_model('random:minilm-l6', 'cross', device, dtype=torch.float32, native=True, split_gemm=True,
+                                   split_dtype=torch.float16)
+        if reranker.endswith('screened'):
+            native_screen, _, _ = bert.load_model('random:minilm-l6', 'cross', device, dtype=torch.float16, native=True)
     if device != 'cpu':
         rag_hip.init(0)
     dv = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(device)
-    screen = None
+    screen = native_screen
     if reranker == 'cross-screened':
         # the screen-then-rescore rerank: the cheap model is the cross-encoder with its weights rounded to float16
         import copy
@@ -98,6 +105,8 @@ def run_rank(rank, world, port, out_path, fusion='rrf', metric='cosine', reranke
         again = s.search(ids, torch.ones_like(ids), qterms, qoff, int(qoff[-1]),
                          ce_tok, ce_off)
         for k, v in out.items():
+            if k == 'logits' and screen is not None:
+                continue                   # (pairs the screen left out keep their cheap logit there, by design)
             if torch.is_tensor(v):
                 if v.dtype.is_floating_point:
                     assert torch.allclose(v, again[k], atol=1e-5), k

@@ -97,3 +97,17 @@ def test_single_rank_over_rccl_takes_every_exchange(tmp_path, reranker):
     assert torch.equal(one['fused_row'], forced['fused_row']) and torch.equal(one['fused_score'], forced['fused_score'])
     assert torch.equal(one['rows'], forced['rows']) and torch.equal(one['count'], forced['count'])
     assert torch.allclose(one['rerank_score'], forced['rerank_score'], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_packed_cross_encoder_and_the_screen(tmp_path):
+    """The unpadded (packed) cross-encoder route of the real kernels across two ranks, 99 pairs (an odd count: the last
+    rank's share is one shorter than the padded piece that is gathered), with and without the float16 screen."""
+    one = _run(1, str(tmp_path / 'one.pt'), 'rrf', 'cosine', 'cross-native', 'cuda')
+    two = _run(2, str(tmp_path / 'two.pt'), 'rrf', 'cosine', 'cross-native', 'cuda')
+    scr = _run(2, str(tmp_path / 'scr.pt'), 'rrf', 'cosine', 'cross-native-screened', 'cuda')
+    for other in (two, scr):
+        assert torch.equal(one['fused_row'], other['fused_row']) and torch.equal(one['fused_score'], other['fused_score'])
+        assert torch.equal(one['rows'], other['rows']) and torch.equal(one['count'], other['count'])
+        assert torch.allclose(one['rerank_score'], other['rerank_score'], atol=2e-6)
+    assert 0.0 < float(scr['rescored_fraction']) <= 1.0
