@@ -60,7 +60,7 @@ def test_default_rows_make_eight_gpus_the_ten_million_row_configuration():
 
 @pytest.mark.gpu
 def test_gpus_1_through_the_launcher_over_rccl():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', '20000', '--batch', '64',
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--rows', '20000', '--batch', '128',
                         '--no-extras', '--cpu-queries', '0', '--steps', '2', '--warmup', '1', '--embed-arch', 'minilm-l6',
                         '--dim', '384', '--vocab', '5000'],
                        capture_output=True, text=True, timeout=600, env=_clean_env(RAG_DIST_FORCE='1'))
@@ -69,3 +69,5 @@ def test_gpus_1_through_the_launcher_over_rccl():
     assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1
     assert line['config']['rows_total'] == 20000 and line['value'] > 0
     assert '[launcher]' in p.stderr
+    # 128 queries x 50 pairs: the screened rerank ran, its two logit exchanges over RCCL included
+    assert line['rerank_screen'] is not None and 0 < line['rerank_screen']['rescored_fraction'] <= 1
