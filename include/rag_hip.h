@@ -323,7 +323,8 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
  * their GEMMs in hipBLASLt; these entry points are what runs between the GEMMs.        */
 #define RAG_DTYPE_F32   0
 #define RAG_DTYPE_BF16  1
-#define RAG_DTYPE_F16   2   /* only as the 16-bit half type of split-precision operands  */
+#define RAG_DTYPE_F16   2   /* float16: the half type of split-precision operands, and the element type of the
+                             * 16-bit instances of the attention / linear384 / mlp / LayerNorm / embedding kernels */
 #define RAG_ENC_MAX_SEQ 512   /* longest sequence of rag_enc_attention_dev              */
 
 /* Self-attention of n_seq padded sequences: qkv is the packed projection output
@@ -331,7 +332,7 @@ int rag_ce_pair_len_dev(const int64_t* d_query_off, int32_t n_queries, const int
  * sequence i (keys at or beyond it are masked, as BERT's additive attention mask does);
  * out [n_seq][seq_len][n_heads*head_dim] = softmax(Q K^T / sqrt(head_dim)) V per head.
  * Rows of padding positions are written (finite), rows of 32-row blocks that hold only
- * padding are zero.  dtype bf16 (MFMA kernel, fp32 softmax) or fp32 (plain fp32
+ * padding are zero.  dtype bf16 or fp16 (MFMA kernel, fp32 softmax) or fp32 (plain fp32
  * arithmetic); head_dim 32 or 64.                                                        */
 int rag_enc_attention_dev(const void* d_qkv, const int32_t* d_lens, int32_t n_seq, int32_t seq_len,
                           int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
@@ -376,22 +377,23 @@ int rag_enc_attention_split_hl_dev(const float* d_qkv, const float* d_bias, cons
 int rag_enc_mean_pool_dev(const float* d_x, const int32_t* d_cu_seqlens, int32_t n_seq,
                           int64_t total_tokens, int32_t hidden, int32_t normalize, float* d_out,
                           void* stream);
-/* Feed-forward block of a BERT layer in one kernel (bf16, fp32 accumulation):
+/* Feed-forward block of a BERT layer in one kernel (bf16 or fp16 by dtype, fp32 accumulation):
  *   y[m] = LayerNorm(x[m] + GELU(x[m] w1^T + b1) w2^T + b2) * gamma + beta
  * x, y [m][hidden]; w1 [intermediate][hidden], w2 [hidden][intermediate] as nn.Linear stores
  * them (the BertIntermediate / BertOutput sub-layers of the cross-encoder forward behind
  * reference src/reranker/rerank.py:79-84).  The [m][intermediate] activation stays on chip.
- * hidden == 384, intermediate a multiple of 32; y must not alias x.  GELU is the erf form,
+ * hidden == 384, intermediate a multiple of 32 up to 2048 (b1 and rings of three weight chunks per
+ * matrix share the LDS); y must not alias x.  GELU is the erf form,
  * evaluated to 4e-5 absolute.                                                            */
 int rag_enc_mlp_dev(const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2,
                     const void* d_b2, const void* d_gamma, const void* d_beta, float eps, int64_t m,
                     int32_t hidden, int32_t intermediate, int32_t dtype, void* d_y, void* stream);
-/* The rest of a BERT layer after self-attention in one kernel (bf16, fp32 accumulation):
+/* The rest of a BERT layer after self-attention in one kernel (bf16 or fp16, fp32 accumulation):
  *   x1   = LayerNorm(x[m] + ctx[m] wo^T + bo) * gamma1 + beta1      (BertSelfOutput)
  *   y[m] = LayerNorm(x1 + GELU(x1 w1^T + b1) w2^T + b2) * gamma2 + beta2
  * ctx = attention output, x = the layer's input, both [m][hidden]; wo [hidden][hidden]; the other
  * arguments as in rag_enc_mlp_dev (same reference path, src/reranker/rerank.py:79-84).  x1 is kept
- * on chip, rounded to bf16 as the layer-by-layer forward stores it.  y may alias x or ctx only if
+ * on chip, rounded to the 16-bit type as the layer-by-layer forward stores it.  y may alias x or ctx only if
  * the caller no longer needs them: rows are read before they are written by the same workgroup. */
 int rag_enc_attn_out_mlp_dev(const void* d_ctx, const void* d_x, const void* d_wo, const void* d_bo,
                              const void* d_gamma1, const void* d_beta1, const void* d_w1,
@@ -409,7 +411,7 @@ int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const void* d_gamm
                          const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                          const void* d_gamma2, const void* d_beta2, float eps, int64_t m, int32_t hidden,
                          int32_t intermediate, int32_t dtype, void* d_y, void* stream);
-/* y[m][n] = sum_k x[m][k] w[n][k] + bias[n] for 384-wide inputs (bf16, fp32 accumulation): the
+/* y[m][n] = sum_k x[m][k] w[n][k] + bias[n] for 384-wide inputs (bf16 or fp16, fp32 accumulation): the
  * q|k|v and attention-output projections of the cross-encoder layers (same reference path as
  * rag_enc_mlp_dev).  x [m][384], w [n][384] as nn.Linear stores it, n a multiple of 32; y must not
  * alias x.  With d_residual != NULL (n == 384): y = LayerNorm(that + residual[m]) * gamma + beta,
@@ -508,7 +510,7 @@ int rag_enc_embed_layernorm_split_dev(const int32_t* d_ids, const int32_t* d_typ
                                       int32_t hidden, int32_t vocab, int32_t max_pos, int32_t n_types,
                                       float* d_out, int32_t half_dtype, void* d_out_split, void* stream);
 /* out[r] = LayerNorm(x[r] + residual[r]) * gamma + beta over `hidden` elements per row
- * (residual may be NULL); fp32 arithmetic, inputs/outputs bf16 or fp32 as `dtype` says;
+ * (residual may be NULL); fp32 arithmetic, inputs/outputs bf16, fp16 or fp32 as `dtype` says;
  * hidden a multiple of 8 up to 2048.  out may alias x or residual.                     */
 int rag_enc_add_layernorm_dev(const void* d_x, const void* d_residual, const void* d_gamma,
                               const void* d_beta, float eps, int64_t rows, int32_t hidden,
