@@ -563,12 +563,33 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
 // stores in flight for another image (waiting for them there cost 5 % of the kernel).
 // Measured with the stores removed the q|k|v shape runs 32 % faster, with the weight loads removed 15 %:
 // the 2.3 KB a token this kernel writes, in 32-byte pieces, is what bounds it.
-constexpr int LN_PF = 4;
+#ifndef LN_PF_N
+#define LN_PF_N 4
+#endif
+constexpr int LN_PF = LN_PF_N;
 #ifndef LN_ABLATE_STORE
 #define LN_ABLATE_STORE 0          // measurement builds: results kept alive but not stored
 #endif
+#ifndef LN_PAIR_STORE
+#define LN_PAIR_STORE 1            // 0: every lane stores its own two 16-byte pieces (32 contiguous bytes per row)
+#endif
 #ifndef LN_LATE_STORE
 #define LN_LATE_STORE 1            // 0: stores at the start of the next image, full wait at its end
+#endif
+#ifndef LN_STAMPS
+#define LN_STAMPS 0                // measurement builds: cycle stamps of one wave (rag_enc_linear_debug)
+#endif
+#if LN_STAMPS
+__device__ unsigned long long ln_dbg[8];
+#define LN_STAMP(var) unsigned long long var = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LN_STAMP(var)
+#endif
+#ifndef LN_ABLATE_LDS
+#define LN_ABLATE_LDS 0            // measurement builds: only the first fragments of an image are read
+#endif
+#ifndef LN_ABLATE_BARRIER
+#define LN_ABLATE_BARRIER 0        // measurement builds: no barrier between images
 #endif
 #ifndef LN_ABLATE_DMA
 #define LN_ABLATE_DMA 0            // measurement builds: the images after the first are not loaded
@@ -596,13 +617,18 @@ template <typename E, bool LN>
 __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p) {
     typedef typename El16<E>::x8 e8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // W images [2][32][48 x 16 B], bias fp32 [N]
+    LN_STAMP(tk0);
+#if LN_STAMPS
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int64_t tok = (int64_t)blockIdx.x * ML_BM + wave * 32 + r;
     const int64_t tok_ld = min(tok, p.M - 1);
     const bool live = tok < p.M;
-    const bool wave_live = (int64_t)blockIdx.x * ML_BM + wave * 32 < p.M;   // uniform: the wave issues its stores
+    // uniform: the wave issues both of an image's stores (with a single live row only one of the pair form's)
+    const bool wave_live = (int64_t)blockIdx.x * ML_BM + wave * 32 + (LN_PAIR_STORE ? 1 : 0) < p.M;
     const int n_img = p.N / ML_C;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
@@ -640,11 +666,33 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
     __syncthreads();
 
     e8 out0, out1;                                        // the previous image's results, stored one image later
+#if LN_STAMPS
+    LN_STAMP(tp);
+    unsigned long long st[4] = {0, 0, 0, 0};
+#endif
     auto image = [&](int c, auto buf_c) {
         constexpr int BUF = decltype(buf_c)::value;
+        LN_STAMP(t0);
         auto store_prev = [&]() {
             if (LN_ABLATE_STORE) {
                 asm volatile("" ::"v"(out0), "v"(out1));
+            } else if (!LN && LN_PAIR_STORE) {
+                // A lane holds pieces h and 2 + h (16 bytes each) of its row's 64 bytes.  The lanes of two
+                // neighbouring rows swap one piece each: the even row's lanes send piece 2 + h and get the
+                // odd row's piece h.  Store A then writes the even row from all four lanes, store B the odd
+                // row: 64 contiguous bytes per row and instruction instead of 32.
+                if (c > 0) {
+                    const bool odd = r & 1;
+                    const u32x4 a = __builtin_bit_cast(u32x4, out0), b = __builtin_bit_cast(u32x4, out1);
+                    u32x4 got;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        got[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? a[k] : b[k]), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    const u32x4 va = odd ? got : a, vb = odd ? b : got;
+                    E* base = p.y + (tok & ~(int64_t)1) * p.N + (c - 1) * ML_C + (odd ? 16 : 0) + 8 * h;
+                    if ((tok & ~(int64_t)1) < p.M) *reinterpret_cast<u32x4*>(base) = va;
+                    if ((tok | 1) < p.M) *reinterpret_cast<u32x4*>(base + p.N) = vb;
+                }
             } else if (c > 0 && live) {
                 *reinterpret_cast<e8*>(yrow + (c - 1) * ML_C) = out0;
                 *reinterpret_cast<e8*>(yrow + (c - 1) * ML_C + 16) = out1;
@@ -661,7 +709,8 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
         f32x16 ae, ao;
         auto issue = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
-            lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q[S % (LN_PF + 1)], l1[S & 7]);
+            if constexpr (!LN_ABLATE_LDS || S <= LN_PF)
+                lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q[S % (LN_PF + 1)], l1[S & 7]);
         };
         auto step = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
@@ -682,6 +731,7 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
         };
         unrolled(std::make_integer_sequence<int, LN_PF>{}, issue);
         unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
+        LN_STAMP(t1);
         // registers 8t..8t+7 are features 32c + 16t + 8h + 0..7
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4));
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + c * (ML_C * 4) + 16);
@@ -703,16 +753,21 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
                 rsq += r0 * r0 + r1 * r1;
             }
         }
+        LN_STAMP(t2);
         if constexpr (!LN && LN_LATE_STORE && !LN_ABLATE_STORE) {
             // the two stores were issued behind the image's loads and may stay in flight: loads and stores
             // retire in issue order, so two outstanding operations mean every weight load has landed
             if (c > 0 && wave_live) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!LN_ABLATE_BARRIER) __builtin_amdgcn_s_barrier();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!LN_ABLATE_BARRIER) __syncthreads();
         }
+#if LN_STAMPS
+        LN_STAMP(t3);
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2; st[3] += 1;
+#endif
     };
     for (int c = 0; c < n_img; c += 2) {
         image(c, std::integral_constant<int, 0>{});
@@ -722,6 +777,11 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
         *reinterpret_cast<e8*>(yrow + (n_img - 1) * ML_C) = out0;
         *reinterpret_cast<e8*>(yrow + (n_img - 1) * ML_C + 16) = out1;
     }
+#if LN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LN_STAMP(tk1);
+    if (blockIdx.x == 300 && tid == 64) { ln_dbg[0] = st[0]; ln_dbg[1] = st[1]; ln_dbg[2] = st[2]; ln_dbg[3] = st[3]; ln_dbg[4] = tp - tk0; ln_dbg[5] = tk1 - tp; ln_dbg[6] = tk1 - tk0; ln_dbg[7] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
     if constexpr (LN) {
         // a token's 384 values are split between this lane and its partner in the other half-wave
         rsum += __shfl_xor(rsum, 32, 64);
@@ -744,8 +804,16 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
     }
 }
 
+
 }  // namespace
 
+#if LN_STAMPS
+extern "C" int rag_enc_linear_debug(unsigned long long* out8) {
+    RAG_HIP_TRY(hipDeviceSynchronize());
+    RAG_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(ln_dbg), 8 * sizeof(unsigned long long)));
+    return RAG_OK;
+}
+#endif
 #if ML_STAMPS
 extern "C" int rag_enc_mlp_debug(unsigned long long* out8) {
     RAG_HIP_TRY(hipDeviceSynchronize());
@@ -934,11 +1002,11 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
     const dim3 grid((unsigned)ceil_div64(m, ML_BM));
     auto launch = [&](auto elem) -> int {
         using E = decltype(elem);
-        if (d_residual) RAG_GRANT_LDS((linear384_kernel<E, true>), 80 * 1024);
-        else RAG_GRANT_LDS((linear384_kernel<E, false>), 80 * 1024);
         LinearParamsT<E> p = {};
         p.x = (const E*)d_x; p.w = (const E*)d_w; p.bias = (const E*)d_bias; p.y = (E*)d_y; p.M = m; p.N = n;
         p.residual = (const E*)d_residual; p.gamma = (const E*)d_gamma; p.beta = (const E*)d_beta; p.eps = eps;
+        if (d_residual) RAG_GRANT_LDS((linear384_kernel<E, true>), 80 * 1024);
+        else RAG_GRANT_LDS((linear384_kernel<E, false>), 80 * 1024);
         if (d_residual)
             hipLaunchKernelGGL((linear384_kernel<E, true>), grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
         else

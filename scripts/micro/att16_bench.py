@@ -63,6 +63,16 @@ def main():
         if args.only and name != args.only:
             continue
         ms = timed(fn, args.iters)
+        if name != 'attention' and hasattr(rag_hip.lib(), 'rag_enc_linear_debug'):      # a library built with -DLN_STAMPS=1
+            import ctypes as C
+            out = (C.c_ulonglong * 8)()
+            rag_hip.lib().rag_enc_linear_debug.argtypes = [C.c_void_p]
+            assert rag_hip.lib().rag_enc_linear_debug(out) == 0
+            v = list(out)
+            n = max(v[3], 1)
+            print({'per_image': {'k_steps': v[0] / n, 'bias_and_pack': v[1] / n, 'wait_and_barrier': v[2] / n}, 'images': v[3],
+                   'prologue': v[4], 'loop_and_tail': v[5], 'workgroup': v[6], 'workgroup_100MHz_ticks': v[7],
+                   'clock_GHz': v[6] / max(v[7], 1) / 10})
         print(f'{name} ({args.dtype}): {len(lens)} sequences, {t} tokens, longest {longest}: {ms:.3f} ms, '
               f'{nbytes / ms / 1e6:.0f} GB/s algorithmic', flush=True)
 

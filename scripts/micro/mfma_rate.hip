@@ -46,6 +46,7 @@ void run(int waves_per_simd, float seed) {
 int main() {
     for (float seed : {0.f, 1.37f}) {
         run<4>(1, seed); run<2>(1, seed); run<4>(2, seed); run<4>(4, seed);
+        run<2>(2, seed); run<2>(3, seed); run<2>(4, seed); run<1>(1, seed); run<1>(3, seed);
     }
     return 0;
 }
