@@ -554,10 +554,9 @@ __global__ __launch_bounds__(ML_NT, 1) void mlp_fused_kernel(MlpParamsT<E> p) {
 // The first product of the block above, on its own: a wave owns 32 tokens whose X fragments stay in
 // registers, W streams through LDS in images of 32 output features (the W1 image: swizzled, rows in the
 // swapped order, so registers 8t..8t+7 of the accumulator are features 16t + 8h + 0..7 and the output
-// is stored in 16-byte pieces).  24 MFMAs per image alternate between two accumulators; that keeps an
-// accumulator's MFMAs two apart, half the matrix rate for one wave — but this kernel needs few
-// registers, so TWO workgroups share a CU and the second wave of a SIMD fills the gaps (and the
-// barrier, the weight loads and the stores of the other).  The stores of an image are issued during the
+// is stored in 16-byte pieces).  24 MFMAs per image alternate between two accumulators.  This kernel
+// needs few registers, so TWO workgroups share a CU and the second wave of a SIMD fills the barrier,
+// the weight loads and the stores of the other.  The stores of an image are issued during the
 // next one, BEHIND that image's weight loads: loads and stores retire in issue order, so the counted wait
 // that closes the image (all but the two newest operations) retires the weight loads and leaves the
 // stores in flight for another image (waiting for them there cost 5 % of the kernel).

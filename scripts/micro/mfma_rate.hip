@@ -1,6 +1,6 @@
-// Issue-rate probe: v_mfma_f32_32x32x16_bf16 streams with 1, 2 or 4 waves per SIMD and 4 accumulators per
-// wave (an MFMA that continues an accumulator four MFMAs after the one that wrote it runs at full
-// rate: 2.0-2.1 PFLOP/s with one wave per SIMD; at distance two the rate halves).
+// Issue-rate probe: v_mfma_f32_32x32x16_bf16 streams with 1 to 4 waves per SIMD and 1, 2 or 4 accumulators per
+// wave (an accumulator is continued that many MFMAs after the one that wrote it).  With constant operands every
+// combination reaches 2.0-2.3 PFLOP/s, one accumulator and one wave per SIMD included.
 // Build: hipcc -O3 --offload-arch=gfx950 mfma_rate.hip -o mfma_rate ; run: ./mfma_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
