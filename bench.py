@@ -85,6 +85,8 @@ def parse():
                     help='tuning aid: residual + LayerNorm after the output projection inside the feed-forward kernel '
                          '(the default of the float16 screening forward)')
     ap.add_argument('--ce-no-fused-norm-mlp', action='store_true', help='tuning aid: ... and as a pass of its own there too')
+    ap.add_argument('--ce-no-fused-qkv-attention', action='store_true',
+                    help='tuning aid: q|k|v projection and self-attention of the 16-bit forward as two kernels')
     ap.add_argument('--ce-fused-attn-norm', action='store_true',
                     help='tuning aid: residual + LayerNorm after the output projection inside rag_enc_linear384_dev')
     ap.add_argument('--pipeline', action='store_true',
@@ -378,6 +380,7 @@ def main():
         m.bert.fused_attn_norm = bool(args.ce_fused_attn_norm)
         m.bert.fused_tail = bool(args.ce_fused_attn_out)
         m.bert.fused_norm_mlp = bool(args.ce_fused_norm_mlp) or (kind == 'fp16' and not args.ce_no_fused_norm_mlp)
+        m.bert.fused_qkv_attention = not getattr(args, 'ce_no_fused_qkv_attention', False)
         return m
 
     def make_searcher(model, top_n, with_dist=True, screen=None):

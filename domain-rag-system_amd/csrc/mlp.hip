@@ -36,6 +36,7 @@
 #include <initializer_list>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -804,8 +805,323 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
 }
 
 
+
+// ---- q|k|v projection and self-attention of whole sequences in one kernel ---------------------------
+// The projection above writes 2304 bytes a token that the attention kernel reads back once; here they
+// never leave the chip.  A workgroup of eight waves takes a TILE: up to 256 consecutive tokens of a
+// packed batch that are whole sequences (the host cuts the batch into tiles).  A wave owns 32 tokens,
+// their X fragments in registers as in linear384_kernel; the weight images stream through two LDS
+// buffers in the order q, k, v of head 0, q, k, v of head 1, ...:
+//   q image: the accumulators (features in registers, the wave's tokens in lanes) are, rounded to the
+//            16-bit type, exactly the B fragments Q^T of the score product — they stay in registers;
+//   k image: the same layout, written as rows of the K image in LDS;
+//   v image: computed with the operands swapped (tokens in registers, features in lanes), which is the
+//            orientation of the V^T image: each lane writes four tokens of its feature row at a time.
+// Behind the barrier that closes the v image every wave runs the attention of its 32 queries over the
+// key blocks that hold its queries' sequences (S^T = K Q^T, online softmax in base 2, O^T += V^T P^T, as
+// attention_kernel in encoder.hip), each lane masking the keys outside its own sequence.  The K and V^T
+// images are overwritten by the next head's k and v images, which every wave reaches only through the
+// barrier that closes the next q image, i.e. after all waves have finished this head's attention.
+// HBM traffic: 768 B read and 768 B written per token.
+constexpr int QA_WAVES = 8;
+constexpr int QA_NT = 64 * QA_WAVES;
+constexpr int QA_TILE = 32 * QA_WAVES;                     // tokens of a tile
+constexpr int QA_DPW = ML_W_BYTES / 1024 / QA_WAVES;      // weight loads per wave and image: 3
+constexpr int QA_D = 32;                                   // head size
+constexpr int QA_KROW = QA_D + 8;                          // K rows padded by 16 bytes
+constexpr int QA_VROW = QA_TILE + 4;                       // V^T rows padded by 8 bytes
+constexpr int QA_OFF_BIAS = 2 * ML_W_BYTES;
+constexpr int QA_OFF_K = QA_OFF_BIAS + 4 * 3 * ML_HID;
+constexpr int QA_OFF_V = QA_OFF_K + QA_TILE * QA_KROW * 2;
+constexpr int QA_LDS = QA_OFF_V + QA_D * QA_VROW * 2;      // 90880 bytes
+constexpr float QA_NEG = -1e30f;
+
+#ifndef QA_STAMPS
+#define QA_STAMPS 0                // measurement builds: cycle stamps of one wave (rag_enc_qkv_attention_debug)
+#endif
+#if QA_STAMPS
+__device__ unsigned long long qa_dbg[8];
+#define QA_STAMP(var) unsigned long long var = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define QA_STAMP(var)
+#endif
+
+template <typename E>
+struct QkvAttnParams {
+    const E* x;              // [T][384] layer input
+    const E* w;              // [1152][384] q | k | v projection weights, heads inside each
+    const E* bias;           // [1152]
+    E* out;                  // [T][384] attention output
+    const int32_t* cu;       // [n_seq + 1] token offsets of the packed sequences
+    const int32_t* tile_seq; // [n_tiles + 1] first sequence of every tile
+    int64_t T;
+    int n_seq;
+    float scale;             // log2(e) / sqrt(head size)
+    uint32_t* fault;
+};
+
+template <typename E>
+__global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E> p) {
+    typedef typename El16<E>::x8 e8;
+    typedef E e4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    QA_STAMP(tk0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    // ---- the tile: sequences [sa, sb), tokens [T0, T1)
+    const int sa = p.tile_seq[blockIdx.x], sb = p.tile_seq[blockIdx.x + 1];
+    if (sa < 0 || sb <= sa || sb > p.n_seq) {
+        if (tid == 0) rag_flag(p.fault, RAG_FAULT_SEGMENT);
+        return;
+    }
+    const int64_t T0 = p.cu[sa], T1 = p.cu[sb];
+    if (T0 < 0 || T1 <= T0 || T1 - T0 > QA_TILE || T1 > p.T) {        // not a tile of this batch
+        if (tid == 0) rag_flag(p.fault, RAG_FAULT_SEGMENT);
+        return;
+    }
+    const int ntok = (int)(T1 - T0);
+    const int ltok = wave * 32 + r;                          // this lane's token inside the tile
+    const bool valid = ltok < ntok;
+    const int64_t tok_ld = T0 + min(ltok, ntok - 1);         // lanes past the tile read its last row; never stored
+
+    uint32_t off1[QA_DPW];
+#pragma unroll
+    for (int i = 0; i < QA_DPW; ++i) {
+        const int L = 64 * (wave + QA_WAVES * i) + lane;
+        const int q = L / 48, j1 = (L % 48) ^ (q & 15);
+        const int unit = (q & ~12) | ((q & 4) << 1) | ((q & 8) >> 1);
+        off1[i] = (uint32_t)((unit * ML_HID + j1 * 8) * 2);
+    }
+    // image c = 3 * head + (0: q, 1: k, 2: v) holds weight rows [which * 384 + 32 * head, + 32)
+    auto dma = [&](int c, int buf, int i) {
+        const int head = c / 3, which = c - 3 * head;
+        lds_dma16(lds0 + buf * ML_W_BYTES + 1024 * (wave + QA_WAVES * i),
+                  p.w + (size_t)(which * ML_HID + QA_D * head) * ML_HID, off1[i]);
+    };
+#pragma unroll
+    for (int i = 0; i < QA_DPW; ++i) dma(0, 0, i);
+    for (int i = tid; i < 3 * ML_HID; i += QA_NT) *reinterpret_cast<float*>(smem + QA_OFF_BIAS + 4 * i) = (float)p.bias[i];
+
+    e8 xf[ML_KS];
+    {
+        const E* xrow = p.x + tok_ld * ML_HID + 8 * h;
+#pragma unroll
+        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
+    }
+    // this lane's sequence, as tile-local token range [s0, s1)
+    int s0 = 0, s1 = 0;
+    for (int s = sa; s < sb; ++s) {
+        const int a = (int)(p.cu[s] - T0), b = (int)(p.cu[s + 1] - T0);
+        if (ltok >= a && ltok < b) { s0 = a; s1 = b; }
+    }
+    if (!valid) { s0 = 0; s1 = 0; }
+    // key blocks this wave's queries need (uniform): from the first lane's sequence start to the last valid lane's end
+    const int n_mine = min(32, ntok - wave * 32);            // valid lanes of this wave (<= 0: none)
+    int kb_lo = 0, kb_hi = 0;
+    if (n_mine > 0) {
+        kb_lo = __builtin_amdgcn_readfirstlane(s0) & ~31;
+        kb_hi = __builtin_amdgcn_readlane(s1, n_mine - 1);
+    }
+
+    uint32_t l1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l1[u] = lds0 + r * (ML_HID * 2) + 16 * ((2 * u + h) ^ (r & 15));
+    const unsigned char* bias_s = smem + QA_OFF_BIAS;
+    E* Ks = reinterpret_cast<E*>(smem + QA_OFF_K);
+    E* Vt = reinterpret_cast<E*>(smem + QA_OFF_V);
+    const int dswap = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // the feature that image row r holds
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    e8 qf[2];
+#if QA_STAMPS
+    QA_STAMP(tp);
+    unsigned long long st[4] = {0, 0, 0, 0};
+#endif
+    // one weight image: 24 MFMAs over the X fragments; WHICH = 0 q, 1 k, 2 v
+    auto image = [&](int head, auto which_c, auto buf_c) {
+        constexpr int WHICH = decltype(which_c)::value, BUF = decltype(buf_c)::value;
+        const int c = 3 * head + WHICH;
+        const int cn = min(c + 1, 3 * (ML_HID / QA_D) - 1);
+        u32x4 q[LN_PF + 1];
+        f32x16 ae, ao;
+        QA_STAMP(t0);
+        auto issue = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            lds_read16<BUF * ML_W_BYTES + 256 * (S >> 3)>(q[S % (LN_PF + 1)], l1[S & 7]);
+        };
+        auto step = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (S < QA_DPW) dma(cn, BUF ^ 1, S);
+            if constexpr (S + LN_PF < ML_KS) issue(std::integral_constant<int, S + LN_PF>{});
+            constexpr int newer = ML_KS - 1 - S < LN_PF ? ML_KS - 1 - S : LN_PF;
+            lds_wait<newer>(q[S % (LN_PF + 1)]);
+            const e8 a = __builtin_bit_cast(e8, q[S % (LN_PF + 1)]);
+            // v image: tokens as rows (X is the A operand), features as columns
+            f32x16& acc = (S & 1) ? ao : ae;
+            const f32x16 prev = S < 2 ? zero16 : acc;
+            if constexpr (WHICH == 2) acc = El16<E>::mfma(xf[S], a, prev);
+            else acc = El16<E>::mfma(a, xf[S], prev);
+        };
+        unrolled(std::make_integer_sequence<int, LN_PF>{}, issue);
+        unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
+        QA_STAMP(t1);
+        if constexpr (WHICH == 2) {
+            // register i is token 8 (i >> 2) + 4 h + (i & 3) of the wave, column = feature dswap
+            const float bv = *reinterpret_cast<const float*>(bias_s + 4 * (2 * ML_HID + QA_D * head + dswap));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                e4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (E)(ae[4 * g + j] + ao[4 * g + j] + bv);
+                *reinterpret_cast<e4*>(Vt + dswap * QA_VROW + wave * 32 + 8 * g + 4 * h) = v;
+            }
+        } else {
+            // registers 8t..8t+7 are features 16t + 8h + 0..7 of the lane's token
+            const unsigned char* bp = bias_s + 4 * (WHICH * ML_HID + QA_D * head) + 32 * h;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 16);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 64);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(bp + 80);
+            e8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o0[j] = (E)(ae[j] + ao[j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
+                o1[j] = (E)(ae[8 + j] + ao[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]));
+            }
+            if constexpr (WHICH == 0) {
+                qf[0] = o0;
+                qf[1] = o1;
+            } else {
+                *reinterpret_cast<e8*>(Ks + ltok * QA_KROW + 8 * h) = o0;
+                *reinterpret_cast<e8*>(Ks + ltok * QA_KROW + 16 + 8 * h) = o1;
+            }
+        }
+        QA_STAMP(t2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#if QA_STAMPS
+        QA_STAMP(t3);
+        st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
+#endif
+    };
+
+    auto attention = [&](int head) {
+        if (n_mine <= 0) return;                             // uniform: a wave past the tile's tokens
+        QA_STAMP(ta0);
+        float m_run = QA_NEG, l_run = 0.f;
+        f32x16 o = zero16;
+        for (int kb = kb_lo; kb < kb_hi; kb += 32) {
+            f32x16 sc = zero16;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const e8 a = *reinterpret_cast<const e8*>(Ks + (kb + r) * QA_KROW + 16 * c + 8 * h);
+                sc = El16<E>::mfma(a, qf[c], sc);
+            }
+            // register i is key kb + 8 (i >> 2) + 4 h + (i & 3); keys outside the lane's sequence [s0, s1) are masked:
+            // with lo = s0 - kb - 4h, key i is inside iff (unsigned)(8 (i >> 2) + (i & 3) - lo) < s1 - s0
+            const int lo = s0 - kb - 4 * h;
+            const unsigned span = (unsigned)(s1 - s0);
+            float mx = QA_NEG;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc[i] = (unsigned)((i & 3) + 8 * (i >> 2) - lo) < span ? sc[i] : QA_NEG;
+                mx = fmaxf(mx, sc[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // (scores are taken in units of 1 / scale until the exponent: max and scale commute, scale > 0)
+            const float m_new = fmaxf(m_run, mx * p.scale);
+            // a block may hold no key of this lane's sequence at all (m_new still the stand-in): the subtrahend is
+            // then held at -1e20, so a masked score still lands at 2^-huge = 0 instead of 2^0
+            const float m_sub = -fmaxf(m_new, -1e20f);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], p.scale, m_sub));
+                sum += sc[i];
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 while nothing has been seen
+            l_run = l_run * alpha + sum;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                e8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (E)sc[8 * t + j];
+                const E* vp = Vt + (size_t)r * QA_VROW + kb + 16 * t + 4 * h;
+                const e4 lo = *reinterpret_cast<const e4*>(vp);
+                const e4 hi = *reinterpret_cast<const e4*>(vp + 8);
+                e8 av;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { av[j] = lo[j]; av[4 + j] = hi[j]; }
+                o = El16<E>::mfma(av, pb, o);
+            }
+        }
+        // O^T: rows d = 8g + 4h + j (registers), column = this lane's query; the two lanes of a query swap half of
+        // their groups so that each stores 16-byte pieces (see attention_kernel)
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        uint2 grp[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            e4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (E)(o[4 * g + j] * inv);
+            grp[g] = __builtin_bit_cast(uint2, v);
+        }
+        const uint2 send0 = h ? grp[0] : grp[1], send1 = h ? grp[2] : grp[3];
+        uint2 got0, got1;
+        got0.x = __shfl_xor(send0.x, 32, 64); got0.y = __shfl_xor(send0.y, 32, 64);
+        got1.x = __shfl_xor(send1.x, 32, 64); got1.y = __shfl_xor(send1.y, 32, 64);
+        const uint2 a0 = h ? got0 : grp[0], a1 = h ? grp[1] : got0;
+        const uint2 b0 = h ? got1 : grp[2], b1 = h ? grp[3] : got1;
+        if (valid) {
+            E* dst = p.out + (T0 + ltok) * ML_HID + QA_D * head + 8 * h;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            *reinterpret_cast<uint4*>(dst + 16) = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+#if QA_STAMPS
+        QA_STAMP(ta1);
+        st[3] += ta1 - ta0;
+#endif
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    for (int head = 0; head < ML_HID / QA_D; head += 2) {
+        // image 3 head + which sits in buffer (3 head + which) & 1
+        image(head, I0{}, I0{});
+        image(head, I1{}, I1{});
+        image(head, I2{}, I0{});
+        attention(head);
+        image(head + 1, I0{}, I1{});
+        image(head + 1, I1{}, I0{});
+        image(head + 1, I2{}, I1{});
+        attention(head + 1);
+    }
+#if QA_STAMPS
+    QA_STAMP(tk1);
+    if (blockIdx.x == 300 && tid == 64) { qa_dbg[0] = st[0]; qa_dbg[1] = st[1]; qa_dbg[2] = st[2]; qa_dbg[3] = st[3]; qa_dbg[4] = tp - tk0; qa_dbg[5] = tk1 - tk0; qa_dbg[6] = (unsigned long long)(kb_hi - kb_lo); qa_dbg[7] = (unsigned long long)ntok; }
+#endif
+}
+
 }  // namespace
 
+#if QA_STAMPS
+extern "C" int rag_enc_qkv_attention_debug(unsigned long long* out8) {
+    RAG_HIP_TRY(hipDeviceSynchronize());
+    RAG_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(qa_dbg), 8 * sizeof(unsigned long long)));
+    return RAG_OK;
+}
+#endif
 #if LN_STAMPS
 extern "C" int rag_enc_linear_debug(unsigned long long* out8) {
     RAG_HIP_TRY(hipDeviceSynchronize());
@@ -1010,6 +1326,112 @@ extern "C" int rag_enc_linear384_dev(const void* d_x, const void* d_w, const voi
             hipLaunchKernelGGL((linear384_kernel<E, true>), grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
         else
             hipLaunchKernelGGL((linear384_kernel<E, false>), grid, dim3(ML_NT), lds_bytes, (hipStream_t)stream_, p);
+        return RAG_OK;
+    };
+    const int rc = dtype == RAG_DTYPE_F16 ? launch(f16{}) : launch(bf16{});
+    if (rc) return rc;
+    RAG_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+// Cuts a packed batch into the tiles of rag_enc_qkv_attention_dev on the host: tile_seq[t] = first sequence of tile t,
+// whole sequences while they sum to at most 256 tokens (greedy, in order).  h_cu and h_tile_seq are HOST arrays
+// (n_seq + 1 entries each at most); returns the number of tiles in *n_tiles.
+extern "C" int rag_enc_qkv_attention_tiles(const int64_t* h_cu, int32_t n_seq, int32_t* h_tile_seq, int32_t* n_tiles) {
+    RAG_REQUIRE(h_cu && h_tile_seq && n_tiles && n_seq >= 0, RAG_EINVAL, "rag_enc_qkv_attention_tiles: bad arguments");
+    int t = 0;
+    int64_t start = n_seq ? h_cu[0] : 0;
+    if (n_seq) h_tile_seq[0] = 0;
+    for (int s = 0; s < n_seq; ++s) {
+        const int64_t len = h_cu[s + 1] - h_cu[s];
+        RAG_REQUIRE(len >= 1 && len <= QA_TILE, RAG_ELIMIT,
+                    "rag_enc_qkv_attention_tiles: sequence %d has %lld tokens (1..%d supported)", s, (long long)len, QA_TILE);
+        if (h_cu[s + 1] - start > QA_TILE) {
+            h_tile_seq[++t] = s;
+            start = h_cu[s];
+        }
+    }
+    if (n_seq) h_tile_seq[++t] = n_seq;
+    *n_tiles = t;
+    return RAG_OK;
+}
+
+// Orders the sequences of a batch (h_len[i] tokens each, HOST array) so that consecutive ones fill tiles of 256 tokens
+// well: a tile takes the longest remaining sequence, then again and again the longest one that still fits (lengths
+// bucketed, so the whole pass is linear).  h_order[j] = index of the sequence that comes j-th, h_tile_seq[t] = position
+// in that order of tile t's first sequence (n_tiles + 1 entries); sequences of no tokens come last, in no tile.
+// RAG_ELIMIT if a sequence has more than 256 tokens.
+extern "C" int rag_enc_qkv_attention_pack(const int32_t* h_len, int32_t n, int64_t* h_order, int32_t* h_tile_seq,
+                                          int32_t* n_tiles) {
+    RAG_REQUIRE(h_len && h_order && h_tile_seq && n_tiles && n >= 0, RAG_EINVAL, "rag_enc_qkv_attention_pack: bad arguments");
+    int32_t count[QA_TILE + 2] = {0};
+    for (int i = 0; i < n; ++i) {
+        RAG_REQUIRE(h_len[i] >= 0 && h_len[i] <= QA_TILE, RAG_ELIMIT,
+                    "rag_enc_qkv_attention_pack: sequence %d has %d tokens (at most %d supported)", i, h_len[i], QA_TILE);
+        ++count[h_len[i] + 1];
+    }
+    for (int l = 0; l <= QA_TILE; ++l) count[l + 1] += count[l];          // count[l] = first slot of length l
+    std::vector<int32_t> by_len((size_t)n);
+    {
+        std::vector<int32_t> at(count, count + QA_TILE + 1);
+        for (int i = 0; i < n; ++i) by_len[(size_t)at[h_len[i]]++] = i;    // stable: input order inside a length
+    }
+    int32_t cur[QA_TILE + 1];                                             // next unused slot of every length
+    uint64_t have[(QA_TILE + 64) / 64] = {0};                             // bit l: length l has unused sequences
+    for (int l = 1; l <= QA_TILE; ++l) {
+        cur[l] = count[l];
+        if (count[l + 1] > count[l]) have[l >> 6] |= 1ull << (l & 63);
+    }
+    auto longest_up_to = [&](int cap) -> int {                            // 0 if none
+        for (int w = cap >> 6; w >= 0; --w) {
+            uint64_t m = have[w];
+            if (w == (cap >> 6)) m &= (cap & 63) == 63 ? ~0ull : ((1ull << ((cap & 63) + 1)) - 1);
+            if (m) return (w << 6) + 63 - __builtin_clzll(m);
+        }
+        return 0;
+    };
+    int64_t pos = 0;
+    int t = 0;
+    for (;;) {
+        int l = longest_up_to(QA_TILE);
+        if (l == 0) break;
+        h_tile_seq[t++] = (int32_t)pos;
+        int cap = QA_TILE;
+        while (l > 0) {
+            h_order[pos++] = by_len[(size_t)cur[l]++];
+            if (cur[l] == count[l + 1]) have[l >> 6] &= ~(1ull << (l & 63));
+            cap -= l;
+            l = cap > 0 ? longest_up_to(cap) : 0;
+        }
+    }
+    h_tile_seq[t] = (int32_t)pos;
+    for (int i = count[0]; i < count[1]; ++i) h_order[pos++] = by_len[(size_t)i];
+    *n_tiles = t;
+    return RAG_OK;
+}
+
+extern "C" int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
+                                         int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
+                                         int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_qkv_attention: bf16 or fp16 only");
+    RAG_REQUIRE(head_dim == QA_D && n_heads * head_dim == ML_HID, RAG_ELIMIT,
+                "rag_enc_qkv_attention: %d heads of %d (got %d of %d)", ML_HID / QA_D, QA_D, n_heads, head_dim);
+    RAG_REQUIRE(n_seq >= 0 && n_tiles >= 0 && n_tiles <= n_seq, RAG_EINVAL, "rag_enc_qkv_attention: bad counts");
+    RAG_REQUIRE(total_tokens >= 0 && total_tokens < (1ll << 31), RAG_ELIMIT, "rag_enc_qkv_attention: bad token count");
+    if (n_seq == 0 || n_tiles == 0) return RAG_OK;
+    RAG_REQUIRE(d_x && d_w && d_bias && d_cu_seqlens && d_tile_seq && d_out, RAG_EINVAL, "rag_enc_qkv_attention: null pointer");
+    RAG_REQUIRE(d_x != d_out, RAG_EINVAL, "rag_enc_qkv_attention: out must not alias x");
+    RAG_REQUIRE(aligned16({d_x, d_w, d_out}), RAG_EINVAL, "rag_enc_qkv_attention: pointers must be 16-byte aligned");
+    uint32_t* fault = rag_fault_word();
+    RAG_REQUIRE(fault != nullptr, RAG_EINVAL, "rag_enc_qkv_attention: call rag_init(device) first");
+    auto launch = [&](auto elem) {
+        using E = decltype(elem);
+        RAG_GRANT_LDS((qkv_attention_kernel<E>), QA_LDS);
+        QkvAttnParams<E> p = {};
+        p.x = (const E*)d_x; p.w = (const E*)d_w; p.bias = (const E*)d_bias; p.out = (E*)d_out;
+        p.cu = d_cu_seqlens; p.tile_seq = d_tile_seq; p.T = total_tokens; p.n_seq = n_seq;
+        p.scale = 1.4426950408889634f / sqrtf((float)head_dim); p.fault = fault;
+        hipLaunchKernelGGL((qkv_attention_kernel<E>), dim3((unsigned)n_tiles), dim3(QA_NT), QA_LDS, (hipStream_t)stream_, p);
         return RAG_OK;
     };
     const int rc = dtype == RAG_DTYPE_F16 ? launch(f16{}) : launch(bf16{});

@@ -440,6 +440,17 @@ class BatchSearcher:
         """Longest pairs first: a mini-batch then holds pairs of similar length, and the attention kernel,
         whose LDS image is sized by the mini-batch's longest pair, fits more workgroups per compute unit on
         all but the first one.  A pair's logit does not depend on its place in the stream."""
+        if self._tiles_wanted(model) and my_r.shape[0] >= 1:
+            # 16-bit model whose layers run projection and attention in one kernel over 256-token tiles of whole pairs:
+            # the pairs go in the order that fills those tiles (one copy of the lengths to the host decides it)
+            packed = rag_hip.enc_qkv_attention_pack(plen.cpu().numpy())
+            if packed is not None:
+                order = torch.from_numpy(packed[0]).to(plen.device)
+                sorted_logits = torch.zeros_like(logits_mine)
+                self._ce_packed_stream(model, q_tok, q_off, my_q[order].contiguous(), my_r[order].contiguous(),
+                                       plen[order].contiguous(), sorted_logits, tile_seq=packed[1])
+                logits_mine[order] = sorted_logits
+                return
         if not self.ce_sort_by_length or my_r.shape[0] < 2:
             return self._ce_packed_stream(model, q_tok, q_off, my_q, my_r, plen, logits_mine)
         order = torch.argsort(plen, descending=True, stable=True)
@@ -448,7 +459,14 @@ class BatchSearcher:
                                plen[order].contiguous(), sorted_logits)
         logits_mine[order] = sorted_logits
 
-    def _ce_packed_stream(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine):
+    @staticmethod
+    def _tiles_wanted(model):
+        b = getattr(model, 'bert', None)
+        return (b is not None and getattr(b, 'fused_qkv_attention', False) and getattr(b, 'native_linear', False)
+                and getattr(b, 'native', False) and b.word.weight.dtype in (torch.bfloat16, torch.float16)
+                and b.config.hidden_size == 384 and b.config.num_attention_heads * 32 == 384)
+
+    def _ce_packed_stream(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine, tile_seq=None):
         """Pairs in the given order as unpadded token streams: no padding inside a pair is
         computed at all (bfloat16 model, librag_hip encoder kernels).  The stream is cut at
         pair boundaries into mini-batches of at most `ce_tokens_per_batch` tokens, each rounded
@@ -483,11 +501,25 @@ class BatchSearcher:
                 self._ce_stream_pool.append(torch.cuda.Stream())
             for st in self._ce_stream_pool[:n_streams]:
                 st.wait_stream(main)
+        # with a tile list (tile_seq[t] = first pair of tile t, pairs without tokens behind the last tile) the
+        # mini-batches are cut at tile boundaries
+        tile_tok = cu_host[tile_seq] if tile_seq is not None else None
+        t0 = 0
         p0 = i_batch = 0
         while p0 < n_mine:
             # as many whole pairs as fit the token budget (a single pair always fits: budget >> max_len)
-            p1 = int(np.searchsorted(cu_host, cu_host[p0] + budget, side='right')) - 1
-            p1 = min(max(p1, p0 + 1), n_mine)
+            tiles_dev = None
+            if tile_seq is not None and t0 < len(tile_seq) - 1:
+                t1 = int(np.searchsorted(tile_tok, tile_tok[t0] + budget, side='right')) - 1
+                t1 = min(max(t1, t0 + 1), len(tile_seq) - 1)
+                p1 = int(tile_seq[t1]) if t1 < len(tile_seq) - 1 else n_mine
+                tiles_dev = torch.from_numpy((tile_seq[t0:t1 + 1] - p0).astype(np.int32)).to(dev)
+                t0 = t1
+            elif tile_seq is not None:
+                p1 = n_mine                                  # only pairs without tokens are left
+            else:
+                p1 = int(np.searchsorted(cu_host, cu_host[p0] + budget, side='right')) - 1
+                p1 = min(max(p1, p0 + 1), n_mine)
             total = int(cu_host[p1] - cu_host[p0])
             side = self._ce_stream_pool[i_batch % n_streams] if n_streams > 1 else None
             i_batch += 1
@@ -502,12 +534,14 @@ class BatchSearcher:
                 ids, types, pos = rag_hip.ce_pack_packed_dev(q_tok, q_off, store.tok, store.off, store.row_base,
                                                              my_q[p0:p1], my_r[p0:p1], cu, total, self.ce_max_len,
                                                              self.cls_id, self.sep_id, padded_total=padded)
+                kw = {'tiles': tiles_dev} if tiles_dev is not None else {}
                 if int(np.count_nonzero(cu_host[p0 + 1:p1 + 1] == cu_host[p0:p1])) == 0:
-                    logits_mine[p0:p1] = model.forward_packed(ids, types, pos, cu, longest)
+                    logits_mine[p0:p1] = model.forward_packed(ids, types, pos, cu, longest, **kw)
                 else:                                    # empty slots (row -1) have no tokens and no logit
+                    # (in the tile order they are the last pairs of the last mini-batch: the live pairs keep their numbers)
                     keep = torch.nonzero(lens > 0)[:, 0]
                     cu_live = torch.cat([cu[:-1][keep], cu[-1:]])
-                    logits_mine[p0 + keep] = model.forward_packed(ids, types, pos, cu_live, longest)
+                    logits_mine[p0 + keep] = model.forward_packed(ids, types, pos, cu_live, longest, **kw)
             p0 = p1
         if n_streams > 1:
             for st in self._ce_stream_pool[:n_streams]:

@@ -114,6 +114,8 @@ class BertEncoder(nn.Module):
         self.fused_mlp = True        # bfloat16, hidden 384: feed-forward block in one kernel (rag_enc_mlp_dev)
         self.fused_norm_mlp = False  # ... with the residual + LayerNorm in front of it in the same kernel (rag_enc_norm_mlp_dev): no faster
         self.fused_tail = False      # ... and the attention-output projection + LayerNorm in the same kernel
+        self.fused_qkv_attention = True   # 16-bit, hidden 384, head size 32, a tile list given: q|k|v projection and
+        #                                   self-attention in one kernel (rag_enc_qkv_attention_dev)
 
     @staticmethod
     def pack(input_ids, attention_mask, token_type_ids=None):
@@ -156,9 +158,10 @@ class BertEncoder(nn.Module):
         return x
 
 
-    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len, first_token_only=False):
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len, first_token_only=False, tiles=None):
         """Unpadded batch on the GPU: ids/types/pos int32 [T], sequence i = tokens
-        [cu_seqlens[i], cu_seqlens[i+1]).  Returns hidden states [T, H], or with
+        [cu_seqlens[i], cu_seqlens[i+1]); tiles (int32 on the device, rag_hip.enc_qkv_attention_tiles / _pack of the same
+        sequences) lets 16-bit 384-wide layers run projection and attention in one kernel.  Returns hidden states [T, H], or with
         first_token_only (bfloat16) just the first token's row of every sequence [n_seq, H]:
         the last layer then computes its output projection, feed-forward block and LayerNorms
         for those rows only (identical values; a classifier head reads nothing else).
@@ -183,6 +186,9 @@ class BertEncoder(nn.Module):
                                             self.emb_norm.eps)
         lin = self._linear_split if (self.split_gemm and x.dtype == torch.float32) else self._linear
         last = len(self.layers) - 1
+        one_kernel = (tiles is not None and self.fused_qkv_attention and self.native_linear
+                      and x.dtype in (torch.bfloat16, torch.float16) and c.hidden_size == 384
+                      and c.num_attention_heads * 32 == 384)
         for li, l in enumerate(self.layers):
             if first_token_only and li == last and x.dtype in (torch.bfloat16, torch.float16):
                 ctx = rag_hip.enc_attention_packed_first_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
@@ -191,7 +197,10 @@ class BertEncoder(nn.Module):
                     return self._layer_tail(l, ctx, x)
                 x = self._attn_output(l, ctx, x, lin)
                 return self._feed_forward(l, x, lin)
-            ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
+            if one_kernel:
+                ctx = rag_hip.enc_qkv_attention_dev(x.contiguous(), l.qkv.weight, l.qkv.bias, cu_seqlens, tiles, l.heads)
+            else:
+                ctx = rag_hip.enc_attention_packed_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
             if self._layer_tail_fused(l, x):
                 x = self._layer_tail(l, ctx, x)
                 continue
@@ -499,11 +508,11 @@ class CrossEncoderModel(nn.Module):
         logits = self.classifier(torch.tanh(self.pooler(h[:, 0])))
         return logits.float().squeeze(-1) if logits.shape[-1] == 1 else logits.float()
 
-    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len):
+    def forward_packed(self, ids, types, pos, cu_seqlens, max_seq_len, tiles=None):
         """Logits of an unpadded batch (every sequence non-empty, first token [CLS])."""
         b = self.bert
         if b.word.weight.dtype in (torch.bfloat16, torch.float16) or (b.split_gemm and b.fused_split_tails):
-            cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True)
+            cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len, first_token_only=True, tiles=tiles)
         else:
             cls = b.forward_packed(ids, types, pos, cu_seqlens, max_seq_len)[cu_seqlens[:-1].long()]
         logits = self.classifier(torch.tanh(self.pooler(cls)))

@@ -86,6 +86,9 @@ SIGNATURES = {
     'rag_bm25_build_dev': (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     'rag_bm25_impacts_dev': (_i32, [_vp, _vp, _i64, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     'rag_enc_linear384_dev': (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
+    'rag_enc_qkv_attention_tiles': (_i32, [_vp, _i32, _vp, _vp]),
+    'rag_enc_qkv_attention_pack': (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    'rag_enc_qkv_attention_dev': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_mlp_profile': (_i32, [_i32]),
     'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -1030,6 +1033,58 @@ def enc_linear384_dev(x, weight, bias, residual=None, gamma=None, beta=None, eps
                                       _ptr(gamma, bf), _ptr(beta, bf), float(eps), _enc_dtype(x), _ptr(y), _stream()),
           'rag_enc_linear384_dev')
     return y
+
+
+QKV_ATTENTION_TILE = 256     # tokens of a tile of enc_qkv_attention_dev, and its longest sequence
+
+
+def enc_qkv_attention_tiles(cu_host):
+    """Cuts a packed batch into the tiles of enc_qkv_attention_dev (rag_enc_qkv_attention_tiles): cu_host = token offsets
+    of the sequences on the HOST (int64, n_seq + 1 entries) -> int32 array [n_tiles + 1], entry t = first sequence of
+    tile t; whole sequences, at most 256 tokens a tile."""
+    cu = np.ascontiguousarray(cu_host, dtype=np.int64)
+    n_seq = len(cu) - 1
+    out = np.zeros(max(n_seq, 0) + 1, np.int32)
+    n = C.c_int32(0)
+    check(lib().rag_enc_qkv_attention_tiles(cu.ctypes.data, n_seq, out.ctypes.data, C.addressof(n)),
+          'rag_enc_qkv_attention_tiles')
+    return out[:n.value + 1].copy()
+
+
+def enc_qkv_attention_pack(lens_host):
+    """An order of the sequences (lens_host: tokens of each, on the HOST) in which consecutive ones fill the 256-token
+    tiles of enc_qkv_attention_dev well (rag_enc_qkv_attention_pack) -> (order int64 [n], tile_seq int32 [n_tiles + 1]:
+    position in that order of every tile's first sequence); empty sequences come last, in no tile.  None if a sequence
+    is longer than a tile."""
+    lens = np.ascontiguousarray(lens_host, dtype=np.int32)
+    if lens.size and int(lens.max()) > QKV_ATTENTION_TILE:
+        return None
+    order = np.zeros(lens.size, np.int64)
+    tiles = np.zeros(lens.size + 1, np.int32)
+    n = C.c_int32(0)
+    check(lib().rag_enc_qkv_attention_pack(lens.ctypes.data, lens.size, order.ctypes.data, tiles.ctypes.data, C.addressof(n)),
+          'rag_enc_qkv_attention_pack')
+    return order, tiles[:n.value + 1].copy()
+
+
+def enc_qkv_attention_dev(x, weight, bias, cu_seqlens, tile_seq, n_heads):
+    """Self-attention output of a packed batch straight from the layer input: x [T, 384] bf16 or fp16, weight [1152, 384]
+    and bias [1152] of the q | k | v projection, cu_seqlens [n_seq + 1] int32 and tile_seq (enc_qkv_attention_tiles, int32)
+    on the device -> context [T, 384] (rag_enc_qkv_attention_dev)."""
+    import torch
+    t, k = x.shape
+    if k != 384 or tuple(weight.shape) != (1152, 384) or tuple(bias.shape) != (1152,):
+        raise ValueError("x must be [T, 384], weight [1152, 384] and bias [1152]")
+    dt = x.dtype
+    if not _is_16bit(dt):
+        raise ValueError("enc_qkv_attention_dev handles bfloat16 and float16")
+    out = torch.empty((t, 384), dtype=dt, device=x.device)
+    n_seq, n_tiles = cu_seqlens.shape[0] - 1, tile_seq.shape[0] - 1
+    check(lib().rag_enc_qkv_attention_dev(_ptr(x, dt), _ptr(weight, dt), _ptr(bias, dt), _ptr(cu_seqlens, torch.int32), n_seq, t,
+                                          _ptr(tile_seq, torch.int32), n_tiles, n_heads, 384 // n_heads, _enc_dtype(x),
+                                          _ptr(out), _stream()),
+          'rag_enc_qkv_attention_dev')
+    return out
 
 
 def enc_mlp_profile(enable=True):

@@ -420,6 +420,27 @@ int rag_enc_norm_mlp_dev(const void* d_proj, const void* d_x, const void* d_gamm
 int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, int64_t m, int32_t n,
                           const void* d_residual, const void* d_gamma, const void* d_beta, float eps,
                           int32_t dtype, void* d_y, void* stream);
+/* q|k|v projection and self-attention of a packed batch in ONE kernel (bf16 or fp16, hidden 384, 12 heads of 32):
+ *   out[t] = concat_h softmax(Q_h K_h^T / sqrt(32)) V_h   with   [Q | K | V] = x W^T + bias
+ * — BertSelfAttention of the cross-encoder layers (transformers, reached through CrossEncoder.predict, reference
+ * src/reranker/rerank.py:79-84) without the 2304 bytes a token that rag_enc_linear384_dev would write and
+ * rag_enc_attention_packed_dev read back.  x, out [total_tokens][384]; w [1152][384] and bias [1152] as nn.Linear stores
+ * the concatenated projection (heads inside each of q, k, v); cu_seqlens [n_seq + 1] as in rag_enc_attention_packed_dev.
+ * The batch is processed in TILES of whole, consecutive sequences with at most 256 tokens each: d_tile_seq[t] = first
+ * sequence of tile t, n_tiles + 1 entries on the device, the last one n_seq (or the number of leading sequences that
+ * have tokens).  A tile that is not one (more than 256 tokens, sequences out of order or beyond the batch) is skipped
+ * and flagged (RAG_FAULT_SEGMENT).  out must not alias x.                                                        */
+int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
+                              int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
+                              int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* Host helpers for the tile list of rag_enc_qkv_attention_dev (all arrays on the HOST; no counterpart in the reference,
+ * whose CrossEncoder.predict pads mini-batches of 32 instead).  _tiles cuts the sequences as they come: h_cu [n_seq + 1]
+ * token offsets -> h_tile_seq (room for n_seq + 1 entries), greedy, every sequence 1..256 tokens (RAG_ELIMIT otherwise).
+ * _pack chooses the ORDER as well: h_len [n] tokens of each sequence -> h_order [n] (the sequence that comes j-th) and
+ * h_tile_seq over that order; a tile takes the longest remaining sequence, then repeatedly the longest that still fits;
+ * sequences without tokens come last, in no tile; RAG_ELIMIT if one has more than 256.                         */
+int rag_enc_qkv_attention_tiles(const int64_t* h_cu, int32_t n_seq, int32_t* h_tile_seq, int32_t* n_tiles);
+int rag_enc_qkv_attention_pack(const int32_t* h_len, int32_t n, int64_t* h_order, int32_t* h_tile_seq, int32_t* n_tiles);
 /* Measurement aid (no counterpart in the reference): while enabled, every launch of the
  * feed-forward kernel (rag_enc_mlp_dev, rag_enc_attn_out_mlp_dev) records a HIP event pair on
  * its stream, up to 1024 launches; rag_enc_mlp_profile_read waits for them and returns their

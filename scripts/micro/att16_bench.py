@@ -34,7 +34,8 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--mean', type=float, default=45.0)
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
-    ap.add_argument('--only', default='', help='attention | qkv | out')
+    ap.add_argument('--only', default='', help='attention | qkv | out | fused')
+    ap.add_argument('--pack', action='store_true', help='order the sequences for full tiles instead of longest first')
     args = ap.parse_args()
     import rag_hip
     rag_hip.init(0)
@@ -46,6 +47,9 @@ def main():
         chunk = int(np.clip(np.rint(rng.lognormal(np.log(args.mean), 0.6)), 2, 128)) + 2
         lens.append(chunk + int(rng.integers(8, 25)) + 3)
     lens = np.sort(np.asarray(lens))[::-1].copy()
+    if args.pack:                                          # the order that fills the fused kernel's tiles
+        order, packed_tiles = rag_hip.enc_qkv_attention_pack(lens)
+        lens = lens[order]
     t = int(lens.sum())
     cu = torch.zeros(len(lens) + 1, dtype=torch.int32, device=dev)
     cu[1:] = torch.cumsum(torch.from_numpy(lens).to(dev), 0)
@@ -59,11 +63,29 @@ def main():
     cases = {'attention': (lambda: rag_hip.enc_attention_packed_dev(qkv, cu, longest, 12), t * (2304 + 768)),
              'qkv': (lambda: rag_hip.enc_linear384_dev(x, wqkv, bqkv), t * (768 + 2304)),
              'out': (lambda: rag_hip.enc_linear384_dev(x, wo, bo), t * (768 + 768))}
+    tiles = torch.from_numpy(packed_tiles if args.pack else rag_hip.enc_qkv_attention_tiles(np.concatenate([[0], np.cumsum(lens)]))).to(dev)
+    cases['fused'] = (lambda: rag_hip.enc_qkv_attention_dev(x, wqkv, bqkv, cu, tiles, 12), t * (768 + 768))
+    if not args.only or args.only == 'fused':
+        want = rag_hip.enc_attention_packed_dev(rag_hip.enc_linear384_dev(x, wqkv, bqkv), cu, longest, 12)
+        got = rag_hip.enc_qkv_attention_dev(x, wqkv, bqkv, cu, tiles, 12)
+        torch.cuda.synchronize()
+        rag_hip.check_faults()
+        d = (got.float() - want.float()).abs()
+        print(f'fused vs projection + attention: {tiles.shape[0] - 1} tiles, max abs difference {float(d.max()):.3e}, '
+              f'mean {float(d.mean()):.3e}, mean |value| {float(want.float().abs().mean()):.3e}', flush=True)
     for name, (fn, nbytes) in cases.items():
         if args.only and name != args.only:
             continue
         ms = timed(fn, args.iters)
-        if name != 'attention' and hasattr(rag_hip.lib(), 'rag_enc_linear_debug'):      # a library built with -DLN_STAMPS=1
+        if name == 'fused' and hasattr(rag_hip.lib(), 'rag_enc_qkv_attention_debug'):   # a library built with -DQA_STAMPS=1
+            import ctypes as C
+            out = (C.c_ulonglong * 8)()
+            rag_hip.lib().rag_enc_qkv_attention_debug.argtypes = [C.c_void_p]
+            assert rag_hip.lib().rag_enc_qkv_attention_debug(out) == 0
+            v = list(out)
+            print({'per_tile': {'k_steps_36_images': v[0], 'image_tails': v[1], 'waits_and_barriers': v[2], 'attention_12_heads': v[3],
+                                'prologue': v[4], 'workgroup': v[5]}, 'key_span': v[6], 'tokens': v[7]})
+        if name in ('qkv', 'out') and hasattr(rag_hip.lib(), 'rag_enc_linear_debug'):      # a library built with -DLN_STAMPS=1
             import ctypes as C
             out = (C.c_ulonglong * 8)()
             rag_hip.lib().rag_enc_linear_debug.argtypes = [C.c_void_p]

@@ -491,3 +491,105 @@ def test_float16_cross_encoder_with_native_kernels_is_eight_times_closer_than_bf
     e16, eb = float((h - a).abs().max()), float((l - a).abs().max())
     assert h.dtype == torch.float32 and e16 < 0.35 * eb, (e16, eb)
     assert e16 < 0.02 * float(a.std()) + 1e-3, (e16, float(a.std()))
+
+
+# ---- q|k|v projection + attention in one kernel ------------------------------------------------------------
+def _qa_inputs(lens, dt, seed, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    t = int(np.sum(lens))
+    x = torch.randn((t, 384), generator=g, device=dev).to(dt)
+    w = (torch.randn((1152, 384), generator=g, device=dev) * 0.05).to(dt)
+    b = (torch.randn((1152,), generator=g, device=dev) * 0.1).to(dt)
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    return x, w, b, cu
+
+
+def _qa_exact(x, w, b, lens):
+    """fp64 attention of the 16-bit operands (projection rounded to the 16-bit type as both GPU routes store it)."""
+    qkv = (x.double() @ w.double().t() + b.double()).to(x.dtype).double()
+    out = torch.zeros((x.shape[0], 384), dtype=torch.float64, device=x.device)
+    p0 = 0
+    for n in lens:
+        n = int(n)
+        q, k, v = (qkv[p0:p0 + n, i * 384:(i + 1) * 384].reshape(n, 12, 32).transpose(0, 1) for i in range(3))
+        a = torch.softmax(q @ k.transpose(1, 2) / np.sqrt(32.0), dim=-1) @ v
+        out[p0:p0 + n] = a.transpose(0, 1).reshape(n, 384)
+        p0 += n
+    return out
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
+@pytest.mark.parametrize('packed', [False, True])
+def test_qkv_attention_in_one_kernel(dt, tol, packed):
+    import rag_hip
+    dev = torch.device('cuda:0')
+    rag_hip.init(0)
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([[256, 1, 255, 1, 2, 31, 32, 33, 64, 128, 127, 129, 200, 56, 57],
+                           rng.integers(1, 257, size=40), rng.integers(8, 90, size=120)]).astype(np.int32)
+    if packed:
+        order, tiles = rag_hip.enc_qkv_attention_pack(lens)
+        assert sorted(order.tolist()) == list(range(len(lens)))
+        lens = lens[order]
+    else:
+        tiles = rag_hip.enc_qkv_attention_tiles(np.concatenate([[0], np.cumsum(lens)]))
+    cu_h = np.concatenate([[0], np.cumsum(lens)])
+    assert tiles[0] == 0 and tiles[-1] == len(lens) and np.all(np.diff(tiles) > 0)
+    assert int((cu_h[tiles[1:]] - cu_h[tiles[:-1]]).max()) <= 256
+    if packed:                                               # nearly full tiles
+        assert len(tiles) - 1 <= int(np.ceil(cu_h[-1] / 256 * 1.08)) + 1
+    x, w, b, cu = _qa_inputs(lens, dt, 11, dev)
+    got = rag_hip.enc_qkv_attention_dev(x, w, b, cu, torch.from_numpy(tiles).to(dev), 12)
+    two = rag_hip.enc_attention_packed_dev(rag_hip.enc_linear384_dev(x, w, b), cu, int(lens.max()), 12)
+    torch.cuda.synchronize()
+    rag_hip.check_faults()
+    ref = _qa_exact(x, w, b, lens)
+    err, err_two = (got.double() - ref).abs(), (two.double() - ref).abs()
+    assert float(err.max()) < tol and float(err.mean()) < tol / 20
+    assert float(err.mean()) <= 1.1 * float(err_two.mean()) + 1e-6       # no less accurate than the two kernels
+    assert got.dtype == dt and tuple(got.shape) == (x.shape[0], 384)
+
+
+def test_qkv_attention_rows_behind_the_batch_and_empty_tail():
+    """x may hold more rows than the sequences cover (the packed route rounds its token count up); sequences without
+    tokens behind the last tile are in no tile."""
+    import rag_hip
+    dev = torch.device('cuda:0')
+    rag_hip.init(0)
+    lens = np.array([70, 90, 64, 33, 100, 0, 0], np.int32)
+    order, tiles = rag_hip.enc_qkv_attention_pack(lens)
+    assert order[-2:].tolist() == [5, 6] and tiles[-1] == 5
+    lens = lens[order]
+    x, w, b, cu = _qa_inputs(lens, torch.float16, 3, dev)
+    pad = torch.zeros((59, 384), dtype=torch.float16, device=dev)
+    xp = torch.cat([x, pad])
+    live = cu[:6].contiguous()                               # the five sequences that have tokens
+    got = rag_hip.enc_qkv_attention_dev(xp, w, b, live, torch.from_numpy(tiles).to(dev), 12)
+    torch.cuda.synchronize()
+    rag_hip.check_faults()
+    ref = _qa_exact(x, w, b, lens[:5])
+    assert float((got[:x.shape[0]].double() - ref).abs().max()) < 3e-3
+
+
+def test_qkv_attention_refuses_what_is_not_a_tile():
+    import rag_hip
+    dev = torch.device('cuda:0')
+    rag_hip.init(0)
+    lens = np.array([200, 200, 10], np.int32)
+    x, w, b, cu = _qa_inputs(lens, torch.float16, 4, dev)
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_qkv_attention_tiles(np.array([0, 300], np.int64))       # a sequence longer than a tile
+    assert rag_hip.enc_qkv_attention_pack(np.array([10, 300], np.int32)) is None
+    bad = torch.tensor([0, 2, 3], dtype=torch.int32, device=dev)            # first tile: 400 tokens
+    out = rag_hip.enc_qkv_attention_dev(x, w, b, cu, bad, 12)
+    torch.cuda.synchronize()
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.check_faults()
+    good = rag_hip.enc_qkv_attention_dev(x, w, b, cu, torch.tensor([0, 1, 3], dtype=torch.int32, device=dev), 12)
+    torch.cuda.synchronize()
+    rag_hip.check_faults()
+    assert float((good[400:].double() - _qa_exact(x, w, b, lens)[400:]).abs().max()) < 3e-3
+    with pytest.raises(ValueError):
+        rag_hip.enc_qkv_attention_dev(x.float(), w, b, cu, bad, 12)
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_qkv_attention_dev(x, w, b, cu, torch.tensor([0, 1, 3], dtype=torch.int32, device=dev), 6)   # heads of 64
