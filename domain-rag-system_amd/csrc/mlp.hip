@@ -810,8 +810,9 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
 // The projection above writes 2304 bytes a token that the attention kernel reads back once; here they
 // never leave the chip.  A workgroup of eight waves takes a TILE: up to 256 consecutive tokens of a
 // packed batch that are whole sequences (the host cuts the batch into tiles).  A wave owns 32 tokens,
-// their X fragments in registers as in linear384_kernel; the weight images stream through two LDS
-// buffers in the order q, k, v of head 0, q, k, v of head 1, ...:
+// their X fragments in registers as in linear384_kernel; the weight images stream through a ring of three
+// LDS buffers in the order q, k, v of head 0, q, k, v of head 1, ... (so q images always sit in buffer 0, k in 1,
+// v in 2), each asked for two images before its use (one workgroup per CU: nothing else would cover the wait):
 //   q image: the accumulators (features in registers, the wave's tokens in lanes) are, rounded to the
 //            16-bit type, exactly the B fragments Q^T of the score product — they stay in registers;
 //   k image: the same layout, written as rows of the K image in LDS;
@@ -826,14 +827,18 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
 constexpr int QA_WAVES = 8;
 constexpr int QA_NT = 64 * QA_WAVES;
 constexpr int QA_TILE = 32 * QA_WAVES;                     // tokens of a tile
+constexpr int QA_RING = 3;                                 // weight buffers
 constexpr int QA_DPW = ML_W_BYTES / 1024 / QA_WAVES;      // weight loads per wave and image: 3
 constexpr int QA_D = 32;                                   // head size
 constexpr int QA_KROW = QA_D + 8;                          // K rows padded by 16 bytes
 constexpr int QA_VROW = QA_TILE + 4;                       // V^T rows padded by 8 bytes
-constexpr int QA_OFF_BIAS = 2 * ML_W_BYTES;
+constexpr int QA_OFF_BIAS = QA_RING * ML_W_BYTES;
 constexpr int QA_OFF_K = QA_OFF_BIAS + 4 * 3 * ML_HID;
 constexpr int QA_OFF_V = QA_OFF_K + QA_TILE * QA_KROW * 2;
-constexpr int QA_LDS = QA_OFF_V + QA_D * QA_VROW * 2;      // 90880 bytes
+constexpr int QA_LDS = QA_OFF_V + QA_D * QA_VROW * 2;      // 115456 bytes: one workgroup per CU
+// (A four-wave form with two weight buffers and 128-token tiles, two workgroups per CU whose phases interleave, ran
+// 6 % faster on sequences of up to 128 tokens — 1.43 against 1.52 ms per 1M tokens — and would need the eight-wave
+// form beside it for longer ones; not kept.)
 constexpr float QA_NEG = -1e30f;
 
 #ifndef QA_STAMPS
@@ -903,6 +908,8 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
     };
 #pragma unroll
     for (int i = 0; i < QA_DPW; ++i) dma(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < QA_DPW; ++i) dma(1, 1, i);
     for (int i = tid; i < 3 * ML_HID; i += QA_NT) *reinterpret_cast<float*>(smem + QA_OFF_BIAS + 4 * i) = (float)p.bias[i];
 
     e8 xf[ML_KS];
@@ -944,10 +951,11 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
     unsigned long long st[4] = {0, 0, 0, 0};
 #endif
     // one weight image: 24 MFMAs over the X fragments; WHICH = 0 q, 1 k, 2 v
-    auto image = [&](int head, auto which_c, auto buf_c) {
-        constexpr int WHICH = decltype(which_c)::value, BUF = decltype(buf_c)::value;
+    auto image = [&](int head, auto which_c) {
+        // image c = 3 head + WHICH sits in buffer c % 3 = WHICH; the image two ahead is loaded meanwhile
+        constexpr int WHICH = decltype(which_c)::value, BUF = WHICH, NBUF = (BUF + 2) % QA_RING;
         const int c = 3 * head + WHICH;
-        const int cn = min(c + 1, 3 * (ML_HID / QA_D) - 1);
+        const int cn = min(c + 2, 3 * (ML_HID / QA_D) - 1);    // past the end: the last image again, unused
         u32x4 q[LN_PF + 1];
         f32x16 ae, ao;
         QA_STAMP(t0);
@@ -957,7 +965,7 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
         };
         auto step = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
-            if constexpr (S < QA_DPW) dma(cn, BUF ^ 1, S);
+            if constexpr (S < QA_DPW) dma(cn, NBUF, S);
             if constexpr (S + LN_PF < ML_KS) issue(std::integral_constant<int, S + LN_PF>{});
             constexpr int newer = ML_KS - 1 - S < LN_PF ? ML_KS - 1 - S : LN_PF;
             lds_wait<newer>(q[S % (LN_PF + 1)]);
@@ -1003,8 +1011,11 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
             }
         }
         QA_STAMP(t2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // loads and stores retire in issue order: all but this image's own weight loads have landed, the next
+        // image's among them (the two stores of a head's attention output were issued before these loads)
+        // (the LDS writes of the k and v images above have to have landed as well before the barrier lets others read)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(QA_DPW) : "memory");
+        __builtin_amdgcn_s_barrier();
 #if QA_STAMPS
         QA_STAMP(t3);
         st[0] += t1 - t0; st[1] += t2 - t1; st[2] += t3 - t2;
@@ -1093,20 +1104,13 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
 #endif
     };
 
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    for (int head = 0; head < ML_HID / QA_D; head += 2) {
-        // image 3 head + which sits in buffer (3 head + which) & 1
-        image(head, I0{}, I0{});
-        image(head, I1{}, I1{});
-        image(head, I2{}, I0{});
+    for (int head = 0; head < ML_HID / QA_D; ++head) {
+        image(head, std::integral_constant<int, 0>{});
+        image(head, std::integral_constant<int, 1>{});
+        image(head, std::integral_constant<int, 2>{});
         attention(head);
-        image(head + 1, I0{}, I1{});
-        image(head + 1, I1{}, I0{});
-        image(head + 1, I2{}, I1{});
-        attention(head + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the repeats of the last image: nothing may land in LDS behind the workgroup
 #if QA_STAMPS
     QA_STAMP(tk1);
     if (blockIdx.x == 300 && tid == 64) { qa_dbg[0] = st[0]; qa_dbg[1] = st[1]; qa_dbg[2] = st[2]; qa_dbg[3] = st[3]; qa_dbg[4] = tp - tk0; qa_dbg[5] = tk1 - tk0; qa_dbg[6] = (unsigned long long)(kb_hi - kb_lo); qa_dbg[7] = (unsigned long long)ntok; }
@@ -1426,11 +1430,11 @@ extern "C" int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const
     RAG_REQUIRE(fault != nullptr, RAG_EINVAL, "rag_enc_qkv_attention: call rag_init(device) first");
     auto launch = [&](auto elem) {
         using E = decltype(elem);
-        RAG_GRANT_LDS((qkv_attention_kernel<E>), QA_LDS);
         QkvAttnParams<E> p = {};
         p.x = (const E*)d_x; p.w = (const E*)d_w; p.bias = (const E*)d_bias; p.out = (E*)d_out;
         p.cu = d_cu_seqlens; p.tile_seq = d_tile_seq; p.T = total_tokens; p.n_seq = n_seq;
         p.scale = 1.4426950408889634f / sqrtf((float)head_dim); p.fault = fault;
+        RAG_GRANT_LDS((qkv_attention_kernel<E>), QA_LDS);
         hipLaunchKernelGGL((qkv_attention_kernel<E>), dim3((unsigned)n_tiles), dim3(QA_NT), QA_LDS, (hipStream_t)stream_, p);
         return RAG_OK;
     };

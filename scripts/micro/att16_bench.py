@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--mean', type=float, default=45.0)
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--only', default='', help='attention | qkv | out | fused')
+    ap.add_argument('--clip', type=int, default=0, help='cut every sequence to this many tokens')
     ap.add_argument('--pack', action='store_true', help='order the sequences for full tiles instead of longest first')
     args = ap.parse_args()
     import rag_hip
@@ -47,6 +48,8 @@ def main():
         chunk = int(np.clip(np.rint(rng.lognormal(np.log(args.mean), 0.6)), 2, 128)) + 2
         lens.append(chunk + int(rng.integers(8, 25)) + 3)
     lens = np.sort(np.asarray(lens))[::-1].copy()
+    if args.clip:
+        lens = np.minimum(lens, args.clip)
     if args.pack:                                          # the order that fills the fused kernel's tiles
         order, packed_tiles = rag_hip.enc_qkv_attention_pack(lens)
         lens = lens[order]
