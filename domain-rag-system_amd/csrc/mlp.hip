@@ -835,7 +835,9 @@ constexpr int QA_VROW = QA_TILE + 4;                       // V^T rows padded by
 constexpr int QA_OFF_BIAS = QA_RING * ML_W_BYTES;
 constexpr int QA_OFF_K = QA_OFF_BIAS + 4 * 3 * ML_HID;
 constexpr int QA_OFF_V = QA_OFF_K + QA_TILE * QA_KROW * 2;
-constexpr int QA_LDS = QA_OFF_V + QA_D * QA_VROW * 2;      // 115456 bytes: one workgroup per CU
+constexpr int QA_OFF_KC = QA_OFF_V + QA_D * QA_VROW * 2;   // sequence codes of the tile's tokens, [256][16]
+constexpr int QA_LDS = QA_OFF_KC + QA_TILE * 16 * 2;       // 123648 bytes: one workgroup per CU
+constexpr float QA_CODE = 2048.f;                          // weight of a code bit in the score
 // (A four-wave form with two weight buffers and 128-token tiles, two workgroups per CU whose phases interleave, ran
 // 6 % faster on sequences of up to 128 tokens — 1.43 against 1.52 ms per 1M tokens — and would need the eight-wave
 // form beside it for longer ones; not kept.)
@@ -919,12 +921,30 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
         for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
     }
     // this lane's sequence, as tile-local token range [s0, s1)
-    int s0 = 0, s1 = 0;
+    int s0 = 0, s1 = 0, sid = 0;                              // sid: 1 + index of the sequence in the tile, 0 = no token
     for (int s = sa; s < sb; ++s) {
         const int a = (int)(p.cu[s] - T0), b = (int)(p.cu[s + 1] - T0);
-        if (ltok >= a && ltok < b) { s0 = a; s1 = b; }
+        if (ltok >= a && ltok < b) { s0 = a; s1 = b; sid = s - sa + 1; }
     }
-    if (!valid) { s0 = 0; s1 = 0; }
+    if (!valid) { s0 = 0; s1 = 0; sid = 0; }
+    // Keys of other sequences are masked BY THE MATRIX UNIT: every token carries a 16-wide code — bits 0..8 of sid
+    // as +-1, then a 1 — and every query the same bits times QA_CODE, then -9 QA_CODE.  The product of a key's and a
+    // query's code is 0 for the same sequence and at most -2 QA_CODE otherwise (all terms are integers: exact), and
+    // is taken as a third k-step of the score product, first, into the zero accumulator.  A masked score then sits
+    // 4096 below any real one: its weight 2^(-4096 scale) is exactly 0.  (16 compare-and-select pairs per key block
+    // and lane otherwise.)
+    e8 qc;
+    {
+        e8 kc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int bit = 8 * h + j;
+            const float sgn = ((sid >> bit) & 1) ? 1.f : -1.f;
+            kc[j] = (E)(bit < 9 ? sgn : bit == 9 ? 1.f : 0.f);
+            qc[j] = (E)(bit < 9 ? sgn * QA_CODE : bit == 9 ? -9.f * QA_CODE : 0.f);
+        }
+        *reinterpret_cast<e8*>(smem + QA_OFF_KC + (ltok * 16 + 8 * h) * 2) = kc;
+    }
     // key blocks this wave's queries need (uniform): from the first lane's sequence start to the last valid lane's end
     const int n_mine = min(32, ntok - wave * 32);            // valid lanes of this wave (<= 0: none)
     int kb_lo = 0, kb_hi = 0;
@@ -1022,46 +1042,45 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
 #endif
     };
 
+    // both lanes of a query (32 apart) combine their halves: one cross-half swap instruction, no LDS round trip
+    auto both_max = [](float v) {
+        const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+    };
+    auto both_sum = [](float v) {
+        const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+    };
     auto attention = [&](int head) {
         if (n_mine <= 0) return;                             // uniform: a wave past the tile's tokens
         QA_STAMP(ta0);
         float m_run = QA_NEG, l_run = 0.f;
         f32x16 o = zero16;
-        for (int kb = kb_lo; kb < kb_hi; kb += 32) {
-            f32x16 sc = zero16;
+        // S^T of one key block: rows = keys kb..kb+31 (register i is key kb + 8 (i >> 2) + 4 h + (i & 3)), column =
+        // this lane's query; the code product first, into the zero accumulator
+        auto scores = [&](int kb) {
+            f32x16 sc = El16<E>::mfma(*reinterpret_cast<const e8*>(smem + QA_OFF_KC + ((kb + r) * 16 + 8 * h) * 2), qc, zero16);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const e8 a = *reinterpret_cast<const e8*>(Ks + (kb + r) * QA_KROW + 16 * c + 8 * h);
                 sc = El16<E>::mfma(a, qf[c], sc);
             }
-            // register i is key kb + 8 (i >> 2) + 4 h + (i & 3); keys outside the lane's sequence [s0, s1) are masked:
-            // with lo = s0 - kb - 4h, key i is inside iff (unsigned)(8 (i >> 2) + (i & 3) - lo) < s1 - s0
-            const int lo = s0 - kb - 4 * h;
-            const unsigned span = (unsigned)(s1 - s0);
-            float mx = QA_NEG;
+            return sc;
+        };
+        auto block_max = [&](const f32x16& sc) {
+            float mx = sc[0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                sc[i] = (unsigned)((i & 3) + 8 * (i >> 2) - lo) < span ? sc[i] : QA_NEG;
-                mx = fmaxf(mx, sc[i]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // (scores are taken in units of 1 / scale until the exponent: max and scale commute, scale > 0)
-            const float m_new = fmaxf(m_run, mx * p.scale);
-            // a block may hold no key of this lane's sequence at all (m_new still the stand-in): the subtrahend is
-            // then held at -1e20, so a masked score still lands at 2^-huge = 0 instead of 2^0
-            const float m_sub = -fmaxf(m_new, -1e20f);
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[i]);
+            return mx;
+        };
+        // weights 2^(score scale - m), their sum (this lane's half), and O^T += V^T P^T
+        auto weigh = [&](f32x16& sc, int kb, float m_new) {
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                sc[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], p.scale, m_sub));
+                sc[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], p.scale, -m_new));
                 sum += sc[i];
             }
-            sum += __shfl_xor(sum, 32, 64);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 while nothing has been seen
-            l_run = l_run * alpha + sum;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] *= alpha;
-            m_run = m_new;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 e8 pb;
@@ -1075,6 +1094,30 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
                 for (int j = 0; j < 4; ++j) { av[j] = lo[j]; av[4 + j] = hi[j]; }
                 o = El16<E>::mfma(av, pb, o);
             }
+            return sum;
+        };
+        // Two key blocks per step while there are two: their score products, exponentials and value products are
+        // independent of each other, and the running maximum / sum are brought up to date once per 64 keys.  Scores
+        // are taken in units of 1 / scale until the exponent (max and scale commute, scale > 0).  A block may hold no
+        // key of this lane's sequence: its weights are then spread over masked keys, and vanish exactly when the first
+        // real key raises the running maximum by thousands (alpha = 0); a lane without any key (past the tile) is
+        // never stored.
+        for (int kb = kb_lo; kb < kb_hi; kb += 64) {
+            const bool two = kb + 32 < kb_hi;                // uniform
+            f32x16 sa2 = scores(kb), sb2 = zero16;
+            float mx = block_max(sa2);
+            if (two) {
+                sb2 = scores(kb + 32);
+                mx = fmaxf(mx, block_max(sb2));
+            }
+            const float m_new = fmaxf(m_run, both_max(mx) * p.scale);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 at the first step: nothing to keep yet
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] *= alpha;
+            float sum = weigh(sa2, kb, m_new);
+            if (two) sum += weigh(sb2, kb + 32, m_new);
+            l_run = l_run * alpha + both_sum(sum);
+            m_run = m_new;
         }
         // O^T: rows d = 8g + 4h + j (registers), column = this lane's query; the two lanes of a query swap half of
         // their groups so that each stores 16-byte pieces (see attention_kernel)
