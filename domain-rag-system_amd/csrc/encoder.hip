@@ -104,6 +104,29 @@ template <> struct Vec8<float> {
 
 constexpr int LN_MAX_CHUNKS = 4;     // 8-element chunks per lane: hidden sizes up to 2048
 
+// The two lanes of a query (32 apart) combine or trade registers with one cross-half swap instruction
+// (v_permlane32_swap: the upper half of the first operand changes places with the lower half of the second) instead
+// of a round trip through the LDS crossbar.
+__device__ __forceinline__ float both_halves_max(float v) {
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float both_halves_sum(float v) {
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+// afterwards the lower lane holds (its a, the upper lane's a) and the upper lane (the lower lane's b, its b)
+__device__ __forceinline__ void trade_halves(uint32_t& a, uint32_t& b) {
+    const auto r2 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r2[0];
+    b = r2[1];
+}
+__device__ __forceinline__ void trade_halves(float& a, float& b) {
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r2[0]);
+    b = __uint_as_float(r2[1]);
+}
+
 // LDS image of one head's keys and values:
 //   K   [kpad][D + 8]     rows padded by 16 B: the 16-byte operand reads of 32 keys spread over the banks
 //   V^T [D][kpad + 4]     rows padded by 8 B: 32 lanes read 8 B of 32 different d rows without conflict
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
                     mx = fmaxf(mx, s[i]);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = both_halves_max(mx);
             const float m_new = fmaxf(m_run, mx);
             float sum = 0.f;
 #pragma unroll
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
                 s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);      // masked keys: 2^(-1e30 - m) = 0
                 sum += s[i];
             }
-            sum += __shfl_xor(sum, 32, 64);
+            sum = both_halves_sum(sum);
             if (kb > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run = l_run * alpha + sum;
@@ -314,13 +337,10 @@ __global__ __launch_bounds__(ATT_NT, RAG_ATT_MIN_BLOCKS) void attention_kernel(c
                 grp[g] = __builtin_bit_cast(uint2, v);
             }
             // lower lane sends groups 1, 3 and keeps 0, 2; upper lane sends 0, 2 and keeps 1, 3
-            const uint2 send0 = h ? grp[0] : grp[1], send1 = h ? grp[2] : grp[3];
-            uint2 got0, got1;
-            got0.x = __shfl_xor(send0.x, 32, 64); got0.y = __shfl_xor(send0.y, 32, 64);
-            got1.x = __shfl_xor(send1.x, 32, 64); got1.y = __shfl_xor(send1.y, 32, 64);
             // 8 elements = (h = 0 part, h = 1 part) of one group: lower g0 then g2, upper g1 then g3
-            const uint2 a0 = h ? got0 : grp[0], a1 = h ? grp[1] : got0;
-            const uint2 b0 = h ? got1 : grp[2], b1 = h ? grp[3] : got1;
+            trade_halves(grp[0].x, grp[1].x); trade_halves(grp[0].y, grp[1].y);
+            trade_halves(grp[2].x, grp[3].x); trade_halves(grp[2].y, grp[3].y);
+            const uint2 a0 = grp[0], a1 = grp[1], b0 = grp[2], b1 = grp[3];
             if (q < n_query_rows) {
                 E* dst = obase + (size_t)q * H + dt * 32 + 8 * h;
                 *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, a1.x, a1.y);
@@ -494,7 +514,7 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
                     mx = fmaxf(mx, s[i]);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = both_halves_max(mx);
             const float m_new = fmaxf(m_run, mx);
             float sum = 0.f;
 #pragma unroll
@@ -504,7 +524,7 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
                 s[i] = __builtin_amdgcn_exp2f(s[i] - m_new);
                 sum += s[i];
             }
-            sum += __shfl_xor(sum, 32, 64);
+            sum = both_halves_sum(sum);
             if (kb > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run = l_run * alpha + sum;
@@ -557,12 +577,12 @@ __global__ __launch_bounds__(ATT_NT, 3) void attention_split_kernel(const float*
             float run[2][8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float got0 = __shfl_xor(h ? grp[0][j] : grp[1][j], 32, 64);
-                const float got1 = __shfl_xor(h ? grp[2][j] : grp[3][j], 32, 64);
-                run[0][j] = h ? got0 : grp[0][j];
-                run[0][4 + j] = h ? grp[1][j] : got0;
-                run[1][j] = h ? got1 : grp[2][j];
-                run[1][4 + j] = h ? grp[3][j] : got1;
+                trade_halves(grp[0][j], grp[1][j]);
+                trade_halves(grp[2][j], grp[3][j]);
+                run[0][j] = grp[0][j];
+                run[0][4 + j] = grp[1][j];
+                run[1][j] = grp[2][j];
+                run[1][4 + j] = grp[3][j];
             }
             if (q < n_query_rows) {
 #pragma unroll

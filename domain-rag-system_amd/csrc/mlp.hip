@@ -1130,12 +1130,16 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
             for (int j = 0; j < 4; ++j) v[j] = (E)(o[4 * g + j] * inv);
             grp[g] = __builtin_bit_cast(uint2, v);
         }
-        const uint2 send0 = h ? grp[0] : grp[1], send1 = h ? grp[2] : grp[3];
-        uint2 got0, got1;
-        got0.x = __shfl_xor(send0.x, 32, 64); got0.y = __shfl_xor(send0.y, 32, 64);
-        got1.x = __shfl_xor(send1.x, 32, 64); got1.y = __shfl_xor(send1.y, 32, 64);
-        const uint2 a0 = h ? got0 : grp[0], a1 = h ? grp[1] : got0;
-        const uint2 b0 = h ? got1 : grp[2], b1 = h ? grp[3] : got1;
+        // (one swap instruction per register: the lower lane then holds its own group and the upper lane's, and
+        // the other way round)
+        auto trade = [](uint32_t& a, uint32_t& b) {
+            const auto r2 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            a = r2[0];
+            b = r2[1];
+        };
+        trade(grp[0].x, grp[1].x); trade(grp[0].y, grp[1].y);
+        trade(grp[2].x, grp[3].x); trade(grp[2].y, grp[3].y);
+        const uint2 a0 = grp[0], a1 = grp[1], b0 = grp[2], b1 = grp[3];
         if (valid) {
             E* dst = p.out + (T0 + ltok) * ML_HID + QA_D * head + 8 * h;
             *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, a1.x, a1.y);
