@@ -1046,7 +1046,7 @@ def enc_qkv_attention_tiles(cu_host):
     n_seq = len(cu) - 1
     out = np.zeros(max(n_seq, 0) + 1, np.int32)
     n = C.c_int32(0)
-    check(lib().rag_enc_qkv_attention_tiles(cu.ctypes.data, n_seq, out.ctypes.data, C.addressof(n)),
+    check(load_library().rag_enc_qkv_attention_tiles(cu.ctypes.data, n_seq, out.ctypes.data, C.addressof(n)),   # host only
           'rag_enc_qkv_attention_tiles')
     return out[:n.value + 1].copy()
 
@@ -1062,7 +1062,7 @@ def enc_qkv_attention_pack(lens_host):
     order = np.zeros(lens.size, np.int64)
     tiles = np.zeros(lens.size + 1, np.int32)
     n = C.c_int32(0)
-    check(lib().rag_enc_qkv_attention_pack(lens.ctypes.data, lens.size, order.ctypes.data, tiles.ctypes.data, C.addressof(n)),
+    check(load_library().rag_enc_qkv_attention_pack(lens.ctypes.data, lens.size, order.ctypes.data, tiles.ctypes.data, C.addressof(n)),
           'rag_enc_qkv_attention_pack')
     return order, tiles[:n.value + 1].copy()
 

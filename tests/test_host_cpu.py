@@ -458,3 +458,42 @@ def test_scripts_build_and_query_1k_chunks_bm25_only(backend, tmp_path, capsys):
     # missing index directory: message, no exception
     a.indices_dir = str(tmp_path / 'nowhere')
     assert query_script.main(a) is None
+
+
+# ---- tile lists of the fused projection + attention kernel (host functions of the library) --------------------
+def test_qkv_attention_tiles_and_pack_on_the_host():
+    import numpy as np
+    import rag_hip
+    rng = np.random.default_rng(9)
+    lens = np.concatenate([rng.integers(1, 257, size=300), [256, 256, 1, 1, 0, 0, 128, 129, 127]]).astype(np.int32)
+    # as they come: greedy, in order (empty sequences are not allowed there)
+    live = lens[lens > 0]
+    cu = np.concatenate([[0], np.cumsum(live)]).astype(np.int64)
+    tiles = rag_hip.enc_qkv_attention_tiles(cu)
+    assert tiles[0] == 0 and tiles[-1] == len(live) and np.all(np.diff(tiles) > 0)
+    tok = cu[tiles]
+    assert int(np.diff(tok).max()) <= 256
+    for t in range(len(tiles) - 2):                          # greedy: the next sequence would not have fitted
+        assert tok[t + 1] - tok[t] + live[tiles[t + 1]] > 256
+    # packed: a permutation, empty sequences last and in no tile, tiles nearly full
+    order, ptiles = rag_hip.enc_qkv_attention_pack(lens)
+    assert sorted(order.tolist()) == list(range(len(lens)))
+    n_live = int((lens > 0).sum())
+    assert ptiles[-1] == n_live and np.all(lens[order[n_live:]] == 0) and np.all(lens[order[:n_live]] > 0)
+    pcu = np.concatenate([[0], np.cumsum(lens[order])])
+    ptok = pcu[ptiles]
+    assert int(np.diff(ptok).max()) <= 256 and np.all(np.diff(ptiles) > 0)
+    assert len(ptiles) - 1 <= len(tiles) - 1                 # never more tiles than taking them as they come
+    assert len(ptiles) - 1 <= int(np.ceil(pcu[-1] / 256 * 1.12))      # lengths uniform in 1..256: many cannot be paired
+    for t in range(len(ptiles) - 1):                         # every tile starts with its longest sequence
+        seg = lens[order[ptiles[t]:ptiles[t + 1]]]
+        assert seg[0] == seg.max()
+    # deterministic, and stable inside a length
+    order2, _ = rag_hip.enc_qkv_attention_pack(lens)
+    assert np.array_equal(order, order2)
+    # limits
+    assert rag_hip.enc_qkv_attention_pack(np.array([5, 257], np.int32)) is None
+    with pytest.raises(rag_hip.RagHipError):
+        rag_hip.enc_qkv_attention_tiles(np.array([0, 10, 10], np.int64))      # an empty sequence
+    o, t = rag_hip.enc_qkv_attention_pack(np.zeros(0, np.int32))
+    assert len(o) == 0 and t.tolist() == [0]
