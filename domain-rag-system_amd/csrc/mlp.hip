@@ -894,6 +894,13 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
     const bool valid = ltok < ntok;
     const int64_t tok_ld = T0 + min(ltok, ntok - 1);         // lanes past the tile read its last row; never stored
 
+    // the X rows first: everything below up to the barrier runs under their flight
+    e8 xf[ML_KS];
+    {
+        const E* xrow = p.x + tok_ld * ML_HID + 8 * h;
+#pragma unroll
+        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
+    }
     uint32_t off1[QA_DPW];
 #pragma unroll
     for (int i = 0; i < QA_DPW; ++i) {
@@ -914,12 +921,6 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
     for (int i = 0; i < QA_DPW; ++i) dma(1, 1, i);
     for (int i = tid; i < 3 * ML_HID; i += QA_NT) *reinterpret_cast<float*>(smem + QA_OFF_BIAS + 4 * i) = (float)p.bias[i];
 
-    e8 xf[ML_KS];
-    {
-        const E* xrow = p.x + tok_ld * ML_HID + 8 * h;
-#pragma unroll
-        for (int t = 0; t < ML_KS; ++t) xf[t] = *reinterpret_cast<const e8*>(xrow + 16 * t);
-    }
     // this lane's sequence, as tile-local token range [s0, s1)
     int s0 = 0, s1 = 0, sid = 0;                              // sid: 1 + index of the sequence in the tile, 0 = no token
     for (int s = sa; s < sb; ++s) {
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
         const int c = 3 * head + WHICH;
         const int cn = min(c + 2, 3 * (ML_HID / QA_D) - 1);    // past the end: the last image again, unused
         u32x4 q[LN_PF + 1];
-        f32x16 ae, ao;
+        f32x16 ae;
         QA_STAMP(t0);
         auto issue = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;
@@ -990,11 +991,11 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
             constexpr int newer = ML_KS - 1 - S < LN_PF ? ML_KS - 1 - S : LN_PF;
             lds_wait<newer>(q[S % (LN_PF + 1)]);
             const e8 a = __builtin_bit_cast(e8, q[S % (LN_PF + 1)]);
-            // v image: tokens as rows (X is the A operand), features as columns
-            f32x16& acc = (S & 1) ? ao : ae;
-            const f32x16 prev = S < 2 ? zero16 : acc;
-            if constexpr (WHICH == 2) acc = El16<E>::mfma(xf[S], a, prev);
-            else acc = El16<E>::mfma(a, xf[S], prev);
+            // v image: tokens as rows (X is the A operand), features as columns.  One accumulator: an MFMA that
+            // continues the accumulator of the one before it issues at the full rate.
+            const f32x16 prev = S == 0 ? zero16 : ae;
+            if constexpr (WHICH == 2) ae = El16<E>::mfma(xf[S], a, prev);
+            else ae = El16<E>::mfma(a, xf[S], prev);
         };
         unrolled(std::make_integer_sequence<int, LN_PF>{}, issue);
         unrolled(std::make_integer_sequence<int, ML_KS>{}, step);
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
             for (int g = 0; g < 4; ++g) {
                 e4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (E)(ae[4 * g + j] + ao[4 * g + j] + bv);
+                for (int j = 0; j < 4; ++j) v[j] = (E)(ae[4 * g + j] + bv);
                 *reinterpret_cast<e4*>(Vt + dswap * QA_VROW + wave * 32 + 8 * g + 4 * h) = v;
             }
         } else {
@@ -1019,8 +1020,8 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
             e8 o0, o1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                o0[j] = (E)(ae[j] + ao[j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
-                o1[j] = (E)(ae[8 + j] + ao[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]));
+                o0[j] = (E)(ae[j] + (j < 4 ? b0[j & 3] : b1[j & 3]));
+                o1[j] = (E)(ae[8 + j] + (j < 4 ? b2[j & 3] : b3[j & 3]));
             }
             if constexpr (WHICH == 0) {
                 qf[0] = o0;
