@@ -62,8 +62,10 @@ def parse():
                          "matrix-core product per product), and only the pairs within a self-checked margin of their query's "
                          "k-th best go through the float32-equivalent forward, from which the final order and scores come; "
                          "'none' = every pair through the float32-equivalent forward")
+    ap.add_argument('--screen-one-stage', action='store_true',
+                    help='tuning aid: the screen with one rescoring forward and a two-sided margin (2 x safety x error)')
     ap.add_argument('--screen-safety', type=float, default=1.5,
-                    help='margin of the screen = 2 x this x the largest within-query difference between cheap and exact logits '
+                    help='margin of the screen = (one stage: 2 x) this x the largest within-query difference between cheap and exact logits '
                          'measured on the rescored pairs')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary measurements (rerank_top_n=30, bf16 cross-encoder, batch sweep, host-buffer run) '
@@ -385,7 +387,7 @@ def main():
 
     def make_searcher(model, top_n, with_dist=True, screen=None):
         return BatchSearcher(dense, bm25, canon=canon, bi_encoder=bi, cross_encoder=model, screen_encoder=screen,
-                             screen_safety=args.screen_safety,
+                             screen_safety=args.screen_safety, screen_two_stage=not args.screen_one_stage,
                              chunk_tokens=TokenStore(tok, off, 0), top_k=args.top_k, rerank_top_n=top_n,
                              ce_pairs_per_batch=args.ce_pairs_per_batch, dist=dist if with_dist else None)
 
@@ -602,13 +604,18 @@ def main():
     if searcher.screen_encoder is not None and screen_after['pairs'] > screen_before['pairs']:
         n_p = screen_after['pairs'] - screen_before['pairs']
         result['rerank_screen'] = {
-            'screen': 'float16 copy of the cross-encoder on every pair (one MFMA product per product); pairs within the margin '
-                      "of their query's k-th best cheap logit are rescored by the float32-equivalent forward; order and "
-                      'rerank_score come from the rescored logits only',
+            'screen': 'float16 copy of the cross-encoder on every pair (one MFMA product per product); '
+                      + ("pairs within the margin of their query's k-th best cheap logit are rescored by the "
+                         'float32-equivalent forward; ' if args.screen_one_stage else
+                         "the k cheap-best of every query are rescored by the float32-equivalent forward, then the pairs whose "
+                         'cheap logit, less the query\'s measured offset, comes within the margin of the k-th best EXACT logit '
+                         'found so far; ')
+                      + 'order and rerank_score come from the rescored logits only',
+            'stages': 1 if args.screen_one_stage else 2,
             'rescored_fraction': round((screen_after['rescored'] - screen_before['rescored']) / n_p, 4),
             'pairs_per_step': n_p // max(args.steps, 1), 'safety': args.screen_safety,
             'within_query_error_max': searcher.screen_stats['err_max'],
-            'margin': 2.0 * args.screen_safety * float(searcher._screen_err or 0.0),
+            'margin': (2.0 if args.screen_one_stage else 1.0) * args.screen_safety * float(searcher._screen_err or 0.0),
             'margin_widened_in_timed_steps': screen_after['widened'] - screen_before['widened']}
     off_h = tok_h = None
 

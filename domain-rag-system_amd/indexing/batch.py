@@ -73,7 +73,7 @@ class BatchSearcher:
                  ce_pairs_per_batch: int = 8192, ce_max_len: int = 512, special_ids=(101, 102, 0), dist=None,
                  ce_packed=None, ce_tokens_per_batch: int = 1 << 20, ce_token_bucket: int = 1 << 17,
                  simple_rerank: bool = False, screen_encoder=None, screen_safety: float = 1.5,
-                 screen_min_safety: float = 1.25, screen_min_pairs: int = 4096):
+                 screen_min_safety: float = 1.25, screen_min_pairs: int = 4096, screen_two_stage: bool = True):
         self.dense, self.bm25, self.canon = dense, bm25, canon
         self.bi_encoder, self.cross_encoder, self.chunk_tokens = bi_encoder, cross_encoder, chunk_tokens
         self.top_k, self.rerank_top_n = int(top_k), int(rerank_top_n)
@@ -105,6 +105,7 @@ class BatchSearcher:
         # and rerank_score come from those exact logits alone.
         self.screen_encoder = screen_encoder if cross_encoder is not None else None
         self.screen_safety, self.screen_min_pairs = float(screen_safety), int(screen_min_pairs)
+        self.screen_two_stage = bool(screen_two_stage)
         self.screen_min_safety = min(float(screen_min_safety), self.screen_safety)
         self._screen_err = None                      # running estimate of the screen's error (None: the next batch rescores every pair)
         self.screen_stats = {'pairs': 0, 'rescored': 0, 'widened': 0, 'batches': 0, 'err_max': 0.0}
@@ -325,24 +326,35 @@ class BatchSearcher:
 
     def _score_screened(self, q_tok, q_off, pair_query, pair_row, live):
         """Screen, then rescore.  Returns (logits [B, T] float32: exact where `rescored`, the screen's elsewhere;
-        rescored [B, T] bool).  The exact top k of a query is certain to lie among its rescored pairs when every pair's
-        cheap logit is within e of its exact one up to an offset c common to the query's pairs (which moves no order):
-        a pair left out has a cheap logit below kth_cheap - 2 s e, hence an exact one below kth_cheap - 2 s e + e - c,
-        while each of the k cheap-best has an exact logit of at least kth_cheap - e - c.  e is not known beforehand: it
-        is measured on the pairs that were rescored (thousands per batch, every one of which has both logits): the
-        margin is 2 * screen_safety * (the running estimate of e), and when the batch's own e shows that this was less
-        than 2 * screen_min_safety * e, the margin is widened to 2 * screen_safety * e and the additional pairs are
-        rescored, so that a margin of at least 2 * screen_min_safety * e holds for every batch that is returned.  Sharded:
-        the cheap logits are gathered first, every rank takes the same decisions, and the chosen pairs are split
-        across the ranks."""
+        rescored [B, T] bool).
+
+        Assumption, the same in both forms below: every pair's cheap logit is within E of its exact one up to an offset
+        common to the query's pairs (which moves no order).  E is not known beforehand; it is measured on the pairs that
+        were rescored — thousands per batch, each with both logits — as the largest deviation e of (cheap - exact) from
+        its median over the query's rescored pairs, and E is taken as screen_safety * (running estimate of e).
+
+        One stage (screen_two_stage False): rescore the pairs with cheap >= kth_cheap - 2 E.  A pair left out has an exact
+        logit below kth_cheap - E - offset, while each of the k cheap-best has one of at least that.
+
+        Two stages (default): first the k cheap-best of every query (and ties).  Their EXACT logits give T, the k-th best
+        exact logit among them — a lower bound of the query's true k-th best, whatever else is rescored later — and the
+        query's offset (median of cheap - exact over them).  A pair that was not rescored can only belong to the true
+        top k if its exact logit reaches T, hence only if cheap >= T + offset - E: those are rescored in a second forward.
+        One E instead of two, because one side of the comparison is now an exact value.
+
+        Either way the batch's own e is compared with the estimate afterwards: if the estimate was below
+        screen_min_safety / screen_safety of what it should have been, the bound is recomputed with the batch's e and
+        the additional pairs are rescored (after three such rounds: every pair).  Sharded: the cheap logits are gathered
+        first, every rank takes the same decisions, and the chosen pairs are split across the ranks."""
         b, t = live.shape
         k = min(self.top_k, t)
         cheap = self._score_pairs(self.screen_encoder, q_tok, q_off, pair_query, pair_row).reshape(b, t)
-        cheap_live = torch.where(live, cheap, torch.full_like(cheap, float('-inf')))
+        neg = torch.full_like(cheap, float('-inf'))
+        nan = torch.full_like(cheap, float('nan'))
+        cheap_live = torch.where(live, cheap, neg)
         kth = torch.topk(cheap_live, k, dim=1).values[:, k - 1:k]               # -inf where a pool has fewer than k pairs
         exact = cheap.clone()
         rescored = torch.zeros_like(live)
-        margin = float('inf') if self._screen_err is None else 2.0 * self.screen_safety * self._screen_err
         widened = 0
 
         def rescore(mask):
@@ -350,22 +362,41 @@ class BatchSearcher:
             if sel.numel():
                 exact.view(-1)[sel] = self._score_pairs(self.cross_encoder, q_tok, q_off, pair_query[sel].contiguous(),
                                                         pair_row[sel].contiguous())
+
+        def wanted(e_used):
+            if e_used is None:                               # first batch: every pair
+                return live & ~rescored
+            if not self.screen_two_stage:
+                return live & ~rescored & ((cheap_live >= kth - 2.0 * self.screen_safety * e_used) | torch.isinf(kth))
+            if not bool(rescored.any()):                     # stage one: the k cheap-best (whole pools that cannot fill a top k)
+                return live & ((cheap_live >= kth) | torch.isinf(kth))
+            t_q = torch.topk(torch.where(rescored, exact, neg), k, dim=1).values[:, k - 1:k]
+            off = torch.nanmedian(torch.where(rescored, cheap - exact, nan), dim=1, keepdim=True).values
+            return live & ~rescored & (cheap_live >= t_q + off - self.screen_safety * e_used)
+
+        e_used = self._screen_err                            # running estimate of e (None: no batch seen yet)
         while True:
-            want = live & ~rescored & ((cheap_live >= kth - margin) | torch.isinf(kth))
+            first = self.screen_two_stage and e_used is not None and not bool(rescored.any())
+            want = wanted(e_used)
             rescore(want)
             rescored |= want
-            # what the margin should have been, from the pairs that now have both logits
-            d = torch.where(rescored, cheap - exact, torch.full_like(cheap, float('nan')))
+            if first:                                        # stage two, from the exact logits of stage one
+                want = wanted(e_used)
+                rescore(want)
+                rescored |= want
+            # what e should have been, from the pairs that now have both logits
+            d = torch.where(rescored, cheap - exact, nan)
             resid = (d - torch.nanmedian(d, dim=1, keepdim=True).values).abs()
             err = float(torch.nan_to_num(resid, nan=0.0).max())
-            if 2.0 * self.screen_min_safety * err <= margin or bool((rescored | ~live).all()):
+            if (e_used is None or self.screen_min_safety * err <= self.screen_safety * e_used
+                    or bool((rescored | ~live).all())):
                 break
             if widened >= 3:                         # still too small after three rounds: take no chances
                 rest = live & ~rescored
                 rescore(rest)
                 rescored |= rest
                 break
-            margin = 2.0 * self.screen_safety * err
+            e_used = err
             widened += 1
         self._screen_err = err if self._screen_err is None else max(err, 0.97 * self._screen_err)
         st = self.screen_stats

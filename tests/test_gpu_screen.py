@@ -1,6 +1,7 @@
 """GPU: the screen-then-rescore rerank (BatchSearcher(screen_encoder=...)) returns what the exact cross-encoder alone
 returns - same final rows in the same order, rerank scores from the exact forward - while scoring only a fraction of
-the pairs exactly; the self-check widens a margin that was too small.  The reference scores every pair in float32 and
+the pairs exactly (in one stage with a two-sided margin, or in two with a bound from the first stage's exact logits);
+the self-check widens a margin that was too small.  The reference scores every pair in float32 and
 sorts (src/reranker/rerank.py:29-43,79-84): only the order and the top_k scores are observable, and those must not move."""
 import numpy as np
 import pytest
@@ -50,15 +51,16 @@ class _Vectors:
         self.v = torch.nn.functional.normalize(torch.randn((b, dim), generator=g, device=dev), dim=1)
 
 
-@pytest.mark.parametrize('init', ['hf-default', 'trained-scale'])
-def test_screened_rerank_equals_the_exact_rerank(init):
+@pytest.mark.parametrize('init,two_stage', [('hf-default', True), ('trained-scale', True), ('hf-default', False)])
+def test_screened_rerank_equals_the_exact_rerank(init, two_stage):
     from indexing.batch import BatchSearcher, TokenStore
     import rag_hip
     dev = torch.device('cuda:0')
     w = _world(dev, init)
     b, top_n = 256, 30
     mk = lambda screen: BatchSearcher(w['dense'], w['bm25'], cross_encoder=w['exact'], screen_encoder=screen,
-                                      chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=top_n)
+                                      chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=top_n,
+                                      screen_two_stage=two_stage)
     plain, screened = mk(None), mk(w['cheap'])
     assert screened.screen_encoder is not None and plain.screen_encoder is None
     fractions = []
