@@ -356,6 +356,7 @@ class BatchSearcher:
         exact = cheap.clone()
         rescored = torch.zeros_like(live)
         widened = 0
+        any_rescored = [False]
 
         def rescore(mask):
             sel = torch.nonzero(mask.reshape(-1))[:, 0]
@@ -368,7 +369,7 @@ class BatchSearcher:
                 return live & ~rescored
             if not self.screen_two_stage:
                 return live & ~rescored & ((cheap_live >= kth - 2.0 * self.screen_safety * e_used) | torch.isinf(kth))
-            if not bool(rescored.any()):                     # stage one: the k cheap-best (whole pools that cannot fill a top k)
+            if not any_rescored[0]:                          # stage one: the k cheap-best (whole pools that cannot fill a top k)
                 return live & ((cheap_live >= kth) | torch.isinf(kth))
             t_q = torch.topk(torch.where(rescored, exact, neg), k, dim=1).values[:, k - 1:k]
             off = torch.nanmedian(torch.where(rescored, cheap - exact, nan), dim=1, keepdim=True).values
@@ -376,10 +377,11 @@ class BatchSearcher:
 
         e_used = self._screen_err                            # running estimate of e (None: no batch seen yet)
         while True:
-            first = self.screen_two_stage and e_used is not None and not bool(rescored.any())
+            first = self.screen_two_stage and e_used is not None and not any_rescored[0]
             want = wanted(e_used)
             rescore(want)
             rescored |= want
+            any_rescored[0] = True                           # (stage one is never empty: a live pair is some query's best)
             if first:                                        # stage two, from the exact logits of stage one
                 want = wanted(e_used)
                 rescore(want)
@@ -474,12 +476,14 @@ class BatchSearcher:
         if self._tiles_wanted(model) and my_r.shape[0] >= 1:
             # 16-bit model whose layers run projection and attention in one kernel over 256-token tiles of whole pairs:
             # the pairs go in the order that fills those tiles (one copy of the lengths to the host decides it)
-            packed = rag_hip.enc_qkv_attention_pack(plen.cpu().numpy())
+            lens_host = plen.cpu().numpy()
+            packed = rag_hip.enc_qkv_attention_pack(lens_host)
             if packed is not None:
                 order = torch.from_numpy(packed[0]).to(plen.device)
                 sorted_logits = torch.zeros_like(logits_mine)
                 self._ce_packed_stream(model, q_tok, q_off, my_q[order].contiguous(), my_r[order].contiguous(),
-                                       plen[order].contiguous(), sorted_logits, tile_seq=packed[1])
+                                       plen[order].contiguous(), sorted_logits, tile_seq=packed[1],
+                                       lens_host=lens_host[packed[0]])
                 logits_mine[order] = sorted_logits
                 return
         if not self.ce_sort_by_length or my_r.shape[0] < 2:
@@ -497,7 +501,7 @@ class BatchSearcher:
                 and getattr(b, 'native', False) and b.word.weight.dtype in (torch.bfloat16, torch.float16)
                 and b.config.hidden_size == 384 and b.config.num_attention_heads * 32 == 384)
 
-    def _ce_packed_stream(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine, tile_seq=None):
+    def _ce_packed_stream(self, model, q_tok, q_off, my_q, my_r, plen, logits_mine, tile_seq=None, lens_host=None):
         """Pairs in the given order as unpadded token streams: no padding inside a pair is
         computed at all (bfloat16 model, librag_hip encoder kernels).  The stream is cut at
         pair boundaries into mini-batches of at most `ce_tokens_per_batch` tokens, each rounded
@@ -509,7 +513,10 @@ class BatchSearcher:
         dev = my_r.device
         cu_all = torch.zeros((n_mine + 1,), dtype=torch.int64, device=dev)
         cu_all[1:] = torch.cumsum(plen, 0)
-        cu_host = cu_all.cpu().numpy()                   # the one host copy of the stage
+        if lens_host is not None:                        # the caller already has the lengths on the host
+            cu_host = np.concatenate([[0], np.cumsum(lens_host, dtype=np.int64)])
+        else:
+            cu_host = cu_all.cpu().numpy()               # the one host copy of the stage
         budget, bucket = self.ce_tokens_per_batch, self.ce_token_bucket
         cb = model.bert
         own_gemms = (getattr(cb, 'native_linear', False) and getattr(cb, 'fused_mlp', False)
@@ -535,6 +542,9 @@ class BatchSearcher:
         # with a tile list (tile_seq[t] = first pair of tile t, pairs without tokens behind the last tile) the
         # mini-batches are cut at tile boundaries
         tile_tok = cu_host[tile_seq] if tile_seq is not None else None
+        # (one upload for the whole stream: a copy from pageable host memory inside the loop would make the host wait for
+        # the mini-batch before it, and the GPU for the host)
+        tile_seq_dev = torch.from_numpy(np.ascontiguousarray(tile_seq, dtype=np.int32)).to(dev) if tile_seq is not None else None
         t0 = 0
         p0 = i_batch = 0
         while p0 < n_mine:
@@ -544,7 +554,7 @@ class BatchSearcher:
                 t1 = int(np.searchsorted(tile_tok, tile_tok[t0] + budget, side='right')) - 1
                 t1 = min(max(t1, t0 + 1), len(tile_seq) - 1)
                 p1 = int(tile_seq[t1]) if t1 < len(tile_seq) - 1 else n_mine
-                tiles_dev = torch.from_numpy((tile_seq[t0:t1 + 1] - p0).astype(np.int32)).to(dev)
+                tiles_dev = tile_seq_dev[t0:t1 + 1] - p0
                 t0 = t1
             elif tile_seq is not None:
                 p1 = n_mine                                  # only pairs without tokens are left
