@@ -867,7 +867,9 @@ struct QkvAttnParams {
     uint32_t* fault;
 };
 
-template <typename E>
+// FIRST: only the first token of every sequence is a query ([CLS] of the last layer, the one row the pooler reads);
+// out is then [n_seq][384], row = sequence.
+template <typename E, bool FIRST>
 __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E> p) {
     typedef typename El16<E>::x8 e8;
     typedef E e4 __attribute__((ext_vector_type(4)));
@@ -947,9 +949,19 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
         *reinterpret_cast<e8*>(smem + QA_OFF_KC + (ltok * 16 + 8 * h) * 2) = kc;
     }
     // key blocks this wave's queries need (uniform): from the first lane's sequence start to the last valid lane's end
-    const int n_mine = min(32, ntok - wave * 32);            // valid lanes of this wave (<= 0: none)
+    int n_mine = min(32, ntok - wave * 32);                  // valid lanes of this wave (<= 0: none)
     int kb_lo = 0, kb_hi = 0;
-    if (n_mine > 0) {
+    const bool stores = valid && (!FIRST || ltok == s0);     // this lane's query is wanted
+    if constexpr (FIRST) {
+        // only the sequences that START in this wave's 32 tokens matter: from the first such lane's start to the last one's end
+        const uint32_t starts = (uint32_t)__builtin_amdgcn_ballot_w64(stores);      // lanes 0..31 (the upper half repeats them)
+        if (starts == 0) {
+            n_mine = 0;                                      // no query here: the wave only projects
+        } else {
+            kb_lo = __builtin_amdgcn_readlane(s0, __builtin_ctz(starts)) & ~31;
+            kb_hi = __builtin_amdgcn_readlane(s1, 31 - __builtin_clz(starts));
+        }
+    } else if (n_mine > 0) {
         kb_lo = __builtin_amdgcn_readfirstlane(s0) & ~31;
         kb_hi = __builtin_amdgcn_readlane(s1, n_mine - 1);
     }
@@ -1141,8 +1153,8 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
         trade(grp[0].x, grp[1].x); trade(grp[0].y, grp[1].y);
         trade(grp[2].x, grp[3].x); trade(grp[2].y, grp[3].y);
         const uint2 a0 = grp[0], a1 = grp[1], b0 = grp[2], b1 = grp[3];
-        if (valid) {
-            E* dst = p.out + (T0 + ltok) * ML_HID + QA_D * head + 8 * h;
+        if (stores) {
+            E* dst = p.out + (FIRST ? (int64_t)(sa + sid - 1) : T0 + ltok) * ML_HID + QA_D * head + 8 * h;
             *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, a1.x, a1.y);
             *reinterpret_cast<uint4*>(dst + 16) = make_uint4(b0.x, b0.y, b1.x, b1.y);
         }
@@ -1462,9 +1474,10 @@ extern "C" int rag_enc_qkv_attention_pack(const int32_t* h_len, int32_t n, int64
     return RAG_OK;
 }
 
-extern "C" int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
-                                         int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
-                                         int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+namespace {
+int qkv_attention_launch(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens, int32_t n_seq,
+                         int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles, int32_t n_heads, int32_t head_dim,
+                         int32_t dtype, void* d_out, void* stream_, bool first_only) {
     RAG_REQUIRE(dtype == RAG_DTYPE_BF16 || dtype == RAG_DTYPE_F16, RAG_ELIMIT, "rag_enc_qkv_attention: bf16 or fp16 only");
     RAG_REQUIRE(head_dim == QA_D && n_heads * head_dim == ML_HID, RAG_ELIMIT,
                 "rag_enc_qkv_attention: %d heads of %d (got %d of %d)", ML_HID / QA_D, QA_D, n_heads, head_dim);
@@ -1482,12 +1495,33 @@ extern "C" int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const
         p.x = (const E*)d_x; p.w = (const E*)d_w; p.bias = (const E*)d_bias; p.out = (E*)d_out;
         p.cu = d_cu_seqlens; p.tile_seq = d_tile_seq; p.T = total_tokens; p.n_seq = n_seq;
         p.scale = 1.4426950408889634f / sqrtf((float)head_dim); p.fault = fault;
-        RAG_GRANT_LDS((qkv_attention_kernel<E>), QA_LDS);
-        hipLaunchKernelGGL((qkv_attention_kernel<E>), dim3((unsigned)n_tiles), dim3(QA_NT), QA_LDS, (hipStream_t)stream_, p);
+        if (first_only) {
+            RAG_GRANT_LDS((qkv_attention_kernel<E, true>), QA_LDS);
+            hipLaunchKernelGGL((qkv_attention_kernel<E, true>), dim3((unsigned)n_tiles), dim3(QA_NT), QA_LDS, (hipStream_t)stream_, p);
+        } else {
+            RAG_GRANT_LDS((qkv_attention_kernel<E, false>), QA_LDS);
+            hipLaunchKernelGGL((qkv_attention_kernel<E, false>), dim3((unsigned)n_tiles), dim3(QA_NT), QA_LDS, (hipStream_t)stream_, p);
+        }
         return RAG_OK;
     };
     const int rc = dtype == RAG_DTYPE_F16 ? launch(f16{}) : launch(bf16{});
     if (rc) return rc;
     RAG_HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
+                                         int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
+                                         int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream_) {
+    return qkv_attention_launch(d_x, d_w, d_bias, d_cu_seqlens, n_seq, total_tokens, d_tile_seq, n_tiles, n_heads, head_dim,
+                                dtype, d_out, stream_, false);
+}
+
+extern "C" int rag_enc_qkv_attention_first_dev(const void* d_x, const void* d_w, const void* d_bias,
+                                               const int32_t* d_cu_seqlens, int32_t n_seq, int64_t total_tokens,
+                                               const int32_t* d_tile_seq, int32_t n_tiles, int32_t n_heads, int32_t head_dim,
+                                               int32_t dtype, void* d_out, void* stream_) {
+    return qkv_attention_launch(d_x, d_w, d_bias, d_cu_seqlens, n_seq, total_tokens, d_tile_seq, n_tiles, n_heads, head_dim,
+                                dtype, d_out, stream_, true);
 }

@@ -191,7 +191,11 @@ class BertEncoder(nn.Module):
                       and c.num_attention_heads * 32 == 384)
         for li, l in enumerate(self.layers):
             if first_token_only and li == last and x.dtype in (torch.bfloat16, torch.float16):
-                ctx = rag_hip.enc_attention_packed_first_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
+                if one_kernel:
+                    ctx = rag_hip.enc_qkv_attention_dev(x.contiguous(), l.qkv.weight, l.qkv.bias, cu_seqlens, tiles, l.heads,
+                                                        first_only=True)
+                else:
+                    ctx = rag_hip.enc_attention_packed_first_dev(lin(l.qkv, x), cu_seqlens, max_seq_len, l.heads)
                 x = x[cu_seqlens[:-1].long()]
                 if self._layer_tail_fused(l, x):
                     return self._layer_tail(l, ctx, x)

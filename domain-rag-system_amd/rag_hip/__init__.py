@@ -89,6 +89,7 @@ SIGNATURES = {
     'rag_enc_qkv_attention_tiles': (_i32, [_vp, _i32, _vp, _vp]),
     'rag_enc_qkv_attention_pack': (_i32, [_vp, _i32, _vp, _vp, _vp]),
     'rag_enc_qkv_attention_dev': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'rag_enc_qkv_attention_first_dev': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     'rag_enc_mlp_profile': (_i32, [_i32]),
     'rag_enc_mlp_profile_read': (_i32, [_vp, _vp, _i32, C.POINTER(_i32)]),
     'rag_enc_attn_out_mlp_dev': (_i32, [_vp] * 12 + [C.c_float, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -1067,10 +1068,11 @@ def enc_qkv_attention_pack(lens_host):
     return order, tiles[:n.value + 1].copy()
 
 
-def enc_qkv_attention_dev(x, weight, bias, cu_seqlens, tile_seq, n_heads):
+def enc_qkv_attention_dev(x, weight, bias, cu_seqlens, tile_seq, n_heads, first_only=False):
     """Self-attention output of a packed batch straight from the layer input: x [T, 384] bf16 or fp16, weight [1152, 384]
     and bias [1152] of the q | k | v projection, cu_seqlens [n_seq + 1] int32 and tile_seq (enc_qkv_attention_tiles, int32)
-    on the device -> context [T, 384] (rag_enc_qkv_attention_dev)."""
+    on the device -> context [T, 384] (rag_enc_qkv_attention_dev); first_only: the first token's row of every sequence,
+    [n_seq, 384] (rag_enc_qkv_attention_first_dev)."""
     import torch
     t, k = x.shape
     if k != 384 or tuple(weight.shape) != (1152, 384) or tuple(bias.shape) != (1152,):
@@ -1078,12 +1080,12 @@ def enc_qkv_attention_dev(x, weight, bias, cu_seqlens, tile_seq, n_heads):
     dt = x.dtype
     if not _is_16bit(dt):
         raise ValueError("enc_qkv_attention_dev handles bfloat16 and float16")
-    out = torch.empty((t, 384), dtype=dt, device=x.device)
     n_seq, n_tiles = cu_seqlens.shape[0] - 1, tile_seq.shape[0] - 1
-    check(lib().rag_enc_qkv_attention_dev(_ptr(x, dt), _ptr(weight, dt), _ptr(bias, dt), _ptr(cu_seqlens, torch.int32), n_seq, t,
-                                          _ptr(tile_seq, torch.int32), n_tiles, n_heads, 384 // n_heads, _enc_dtype(x),
-                                          _ptr(out), _stream()),
-          'rag_enc_qkv_attention_dev')
+    out = torch.empty((n_seq if first_only else t, 384), dtype=dt, device=x.device)
+    fn = lib().rag_enc_qkv_attention_first_dev if first_only else lib().rag_enc_qkv_attention_dev
+    check(fn(_ptr(x, dt), _ptr(weight, dt), _ptr(bias, dt), _ptr(cu_seqlens, torch.int32), n_seq, t,
+             _ptr(tile_seq, torch.int32), n_tiles, n_heads, 384 // n_heads, _enc_dtype(x), _ptr(out), _stream()),
+          'rag_enc_qkv_attention_first_dev' if first_only else 'rag_enc_qkv_attention_dev')
     return out
 
 

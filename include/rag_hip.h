@@ -433,6 +433,12 @@ int rag_enc_linear384_dev(const void* d_x, const void* d_w, const void* d_bias, 
 int rag_enc_qkv_attention_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
                               int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
                               int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
+/* The same with only the FIRST token of every sequence as a query (the [CLS] row, all the pooler behind the last layer
+ * reads; as rag_enc_attention_packed_first_dev): out [n_seq][384], row = sequence.  The tile list must cover every
+ * sequence (d_tile_seq[n_tiles] == n_seq).                                                                        */
+int rag_enc_qkv_attention_first_dev(const void* d_x, const void* d_w, const void* d_bias, const int32_t* d_cu_seqlens,
+                                    int32_t n_seq, int64_t total_tokens, const int32_t* d_tile_seq, int32_t n_tiles,
+                                    int32_t n_heads, int32_t head_dim, int32_t dtype, void* d_out, void* stream);
 /* Host helpers for the tile list of rag_enc_qkv_attention_dev (all arrays on the HOST; no counterpart in the reference,
  * whose CrossEncoder.predict pads mini-batches of 32 instead).  _tiles cuts the sequences as they come: h_cu [n_seq + 1]
  * token offsets -> h_tile_seq (room for n_seq + 1 entries), greedy, every sequence 1..256 tokens (RAG_ELIMIT otherwise).

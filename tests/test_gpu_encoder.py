@@ -548,6 +548,14 @@ def test_qkv_attention_in_one_kernel(dt, tol, packed):
     assert float(err.max()) < tol and float(err.mean()) < tol / 20
     assert float(err.mean()) <= 1.1 * float(err_two.mean()) + 1e-6       # no less accurate than the two kernels
     assert got.dtype == dt and tuple(got.shape) == (x.shape[0], 384)
+    # only the first token of every sequence as a query
+    first = rag_hip.enc_qkv_attention_dev(x, w, b, cu, torch.from_numpy(tiles).to(dev), 12, first_only=True)
+    torch.cuda.synchronize()
+    rag_hip.check_faults()
+    rows = torch.from_numpy(cu_h[:-1].astype(np.int64)).to(dev)
+    assert tuple(first.shape) == (len(lens), 384)
+    ef = (first.double() - ref[rows]).abs()
+    assert float(ef.max()) < tol and float(ef.mean()) < tol / 20
 
 
 def test_qkv_attention_rows_behind_the_batch_and_empty_tail():
