@@ -836,7 +836,8 @@ constexpr int QA_OFF_BIAS = QA_RING * ML_W_BYTES;
 constexpr int QA_OFF_K = QA_OFF_BIAS + 4 * 3 * ML_HID;
 constexpr int QA_OFF_V = QA_OFF_K + QA_TILE * QA_KROW * 2;
 constexpr int QA_OFF_KC = QA_OFF_V + QA_D * QA_VROW * 2;   // sequence codes of the tile's tokens, [256][16]
-constexpr int QA_LDS = QA_OFF_KC + QA_TILE * 16 * 2;       // 123648 bytes: one workgroup per CU
+constexpr int QA_OFF_SEQ = QA_OFF_KC + QA_TILE * 16 * 2;   // tile-local start of every sequence of the tile, [257] int32
+constexpr int QA_LDS = QA_OFF_SEQ + (QA_TILE + 4) * 4;     // 124688 bytes: one workgroup per CU
 constexpr float QA_CODE = 2048.f;                          // weight of a code bit in the score
 // (A four-wave form with two weight buffers and 128-token tiles, two workgroups per CU whose phases interleave, ran
 // 6 % faster on sequences of up to 128 tokens — 1.43 against 1.52 ms per 1M tokens — and would need the eight-wave
@@ -924,12 +925,21 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
     for (int i = tid; i < 3 * ML_HID; i += QA_NT) *reinterpret_cast<float*>(smem + QA_OFF_BIAS + 4 * i) = (float)p.bias[i];
 
     // this lane's sequence, as tile-local token range [s0, s1)
+    // (the starts of the tile's sequences go through LDS — one load per thread — and every lane finds its own by
+    // bisection: a loop over the sequences with a scalar load each costs a memory round trip per sequence)
     int s0 = 0, s1 = 0, sid = 0;                              // sid: 1 + index of the sequence in the tile, 0 = no token
-    for (int s = sa; s < sb; ++s) {
-        const int a = (int)(p.cu[s] - T0), b = (int)(p.cu[s + 1] - T0);
-        if (ltok >= a && ltok < b) { s0 = a; s1 = b; sid = s - sa + 1; }
+    {
+        int* seq_start = reinterpret_cast<int*>(smem + QA_OFF_SEQ);
+        const int n_s = sb - sa;                             // <= 256: every sequence has a token
+        for (int i = tid; i <= n_s; i += QA_NT) seq_start[i] = (int)(p.cu[sa + i] - T0);
+        __syncthreads();
+        int lo = 0, hi = n_s;                                // the sequence j with seq_start[j] <= ltok < seq_start[j + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seq_start[mid] <= ltok) lo = mid; else hi = mid;
+        }
+        if (valid) { s0 = seq_start[lo]; s1 = seq_start[lo + 1]; sid = lo + 1; }
     }
-    if (!valid) { s0 = 0; s1 = 0; sid = 0; }
     // Keys of other sequences are masked BY THE MATRIX UNIT: every token carries a 16-wide code — bits 0..8 of sid
     // as +-1, then a 1 — and every query the same bits times QA_CODE, then -9 QA_CODE.  The product of a key's and a
     // query's code is 0 for the same sequence and at most -2 QA_CODE otherwise (all terms are integers: exact), and
