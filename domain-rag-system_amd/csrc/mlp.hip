@@ -883,7 +883,7 @@ __global__ __launch_bounds__(QA_NT, 1) void qkv_attention_kernel(QkvAttnParams<E
 
     // ---- the tile: sequences [sa, sb), tokens [T0, T1)
     const int sa = p.tile_seq[blockIdx.x], sb = p.tile_seq[blockIdx.x + 1];
-    if (sa < 0 || sb <= sa || sb > p.n_seq) {
+    if (sa < 0 || sb <= sa || sb > p.n_seq || sb - sa > QA_TILE) {      // (a sequence has at least one token)
         if (tid == 0) rag_flag(p.fault, RAG_FAULT_SEGMENT);
         return;
     }

@@ -376,6 +376,8 @@ class BatchSearcher:
             return live & ~rescored & (cheap_live >= t_q + off - self.screen_safety * e_used)
 
         e_used = self._screen_err                            # running estimate of e (None: no batch seen yet)
+        if e_used is not None and not bool(torch.isfinite(cheap_live[live]).all()):
+            e_used = None                                    # a float16 overflow in the screen: it decides nothing, every pair is rescored
         while True:
             first = self.screen_two_stage and e_used is not None and not any_rescored[0]
             want = wanted(e_used)
@@ -387,7 +389,7 @@ class BatchSearcher:
                 rescore(want)
                 rescored |= want
             # what e should have been, from the pairs that now have both logits
-            d = torch.where(rescored, cheap - exact, nan)
+            d = torch.where(rescored & torch.isfinite(cheap), cheap - exact, nan)
             resid = (d - torch.nanmedian(d, dim=1, keepdim=True).values).abs()
             err = float(torch.nan_to_num(resid, nan=0.0).max())
             if (e_used is None or self.screen_min_safety * err <= self.screen_safety * e_used

@@ -176,3 +176,40 @@ def test_screened_rerank_with_ragged_and_empty_pools():
     rag_hip.check_faults()
     w['dense'].close()
     w['bm25'].close()
+
+
+def test_a_screen_that_overflows_decides_nothing():
+    """Non-finite cheap logits (a float16 overflow inside the screening forward): every pair is rescored and the result
+    is the exact rerank's."""
+    from indexing.batch import BatchSearcher, TokenStore
+    dev = torch.device('cuda:0')
+    w = _world(dev, 'hf-default', n=8000)
+    b, top_n = 160, 30
+    mk = lambda screen: BatchSearcher(w['dense'], w['bm25'], cross_encoder=w['exact'], screen_encoder=screen,
+                                      chunk_tokens=TokenStore(w['tok'], w['off'], 0), top_k=5, rerank_top_n=top_n)
+    plain, screened = mk(None), mk(w['cheap'])
+    qterms, qoff, n_terms, ce_tok, ce_off = _queries(w, b, 41, dev)
+    qv = _Vectors(b, w['dim'], 42, dev).v
+    fused = plain.fuse(plain.dense_search(qv, 60), plain.bm25_search(qterms, qoff, n_terms, 60), top_n)
+    want = plain.finish(fused, ce_tok, ce_off)
+    screened.finish(fused, ce_tok, ce_off)                   # first batch: sets the error estimate
+    inner = screened._score_pairs
+
+    def spoiled(model, *a, **kw):
+        out = inner(model, *a, **kw)
+        if model is screened.screen_encoder:
+            out = out.clone()
+            out[::7] = float('inf')
+            out[3::11] = float('nan')
+        return out
+    screened._score_pairs = spoiled
+    before = dict(screened.screen_stats)
+    got = screened.finish(fused, ce_tok, ce_off)
+    torch.cuda.synchronize()
+    st = screened.screen_stats
+    assert st['rescored'] - before['rescored'] == st['pairs'] - before['pairs']       # everything was rescored
+    assert torch.equal(got['rows'], want['rows'])
+    assert float((got['rerank_score'] - want['rerank_score']).abs().max()) < 2e-6
+    assert np.isfinite(screened._screen_err)
+    w['dense'].close()
+    w['bm25'].close()
