@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--only', default='', help='attention | qkv | out | fused')
     ap.add_argument('--clip', type=int, default=0, help='cut every sequence to this many tokens')
+    ap.add_argument('--uniform', type=int, default=0, help='every sequence this long (no query block straddles two sequences when it divides 32)')
     ap.add_argument('--pack', action='store_true', help='order the sequences for full tiles instead of longest first')
     args = ap.parse_args()
     import rag_hip
@@ -50,6 +51,8 @@ def main():
     lens = np.sort(np.asarray(lens))[::-1].copy()
     if args.clip:
         lens = np.minimum(lens, args.clip)
+    if args.uniform:
+        lens = np.full(args.tokens // args.uniform, args.uniform)
     if args.pack:                                          # the order that fills the fused kernel's tiles
         order, packed_tiles = rag_hip.enc_qkv_attention_pack(lens)
         lens = lens[order]
