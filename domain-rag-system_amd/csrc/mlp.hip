@@ -820,7 +820,8 @@ __global__ __launch_bounds__(ML_NT, 2) void linear384_kernel(LinearParamsT<E> p)
 //            orientation of the V^T image: each lane writes four tokens of its feature row at a time.
 // Behind the barrier that closes the v image every wave runs the attention of its 32 queries over the
 // key blocks that hold its queries' sequences (S^T = K Q^T, online softmax in base 2, O^T += V^T P^T, as
-// attention_kernel in encoder.hip), each lane masking the keys outside its own sequence.  The K and V^T
+// attention_kernel in encoder.hip; two key blocks per step; keys of other sequences masked by a code product on
+// the matrix unit, see below).  The K and V^T
 // images are overwritten by the next head's k and v images, which every wave reaches only through the
 // barrier that closes the next q image, i.e. after all waves have finished this head's attention.
 // HBM traffic: 768 B read and 768 B written per token.
