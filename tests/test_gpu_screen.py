@@ -213,3 +213,48 @@ def test_a_screen_that_overflows_decides_nothing():
     assert np.isfinite(screened._screen_err)
     w['dense'].close()
     w['bm25'].close()
+
+
+def test_tile_order_and_mini_batch_cuts_do_not_change_a_logit(monkeypatch):
+    """The float16 forward runs its pairs in the order that fills 256-token tiles and cuts the stream into mini-batches
+    at tile boundaries: the same pairs through mini-batches of a few tiles each, through one mini-batch, and through
+    the two-kernel route (no tiles) give the same logits to float16 rounding."""
+    from indexing.batch import BatchSearcher, TokenStore
+    dev = torch.device('cuda:0')
+    w = _world(dev, 'hf-default', n=6000)
+    b, t = 96, 30
+    rng = np.random.default_rng(17)
+    cnt = rng.integers(0, t + 1, size=b)
+    rows = np.full((b, t), -1, np.int64)
+    for i in range(b):
+        rows[i, :cnt[i]] = rng.choice(6000, size=cnt[i], replace=False)
+    fused_row = torch.from_numpy(rows).to(dev)
+    _, _, _, ce_tok, ce_off = _queries(w, b, 19, dev)
+    s = BatchSearcher(w['dense'], w['bm25'], cross_encoder=w['cheap'], chunk_tokens=TokenStore(w['tok'], w['off'], 0),
+                      top_k=5, rerank_top_n=t)
+    pq = torch.arange(b, dtype=torch.int32, device=dev).repeat_interleave(t)
+    pr = fused_row.reshape(-1)
+
+    def logits():
+        with torch.no_grad():
+            out = s._score_pairs(w['cheap'], ce_tok, ce_off, pq, pr)
+        torch.cuda.synchronize()
+        return out
+    assert s._tiles_wanted(w['cheap'])
+    one = logits()
+    monkeypatch.setenv('RAG_CE_TOKENS', '700')               # two or three tiles per mini-batch
+    many = logits()
+    monkeypatch.delenv('RAG_CE_TOKENS')
+    live = (pr >= 0)
+    # (not bit for bit: the library GEMMs of the pooler and the classifier see another row count per mini-batch)
+    assert float((one[live] - many[live]).abs().max()) < 5e-4
+    w['cheap'].bert.fused_qkv_attention = False              # projection and attention as two kernels, pairs longest first
+    try:
+        two = logits()
+    finally:
+        w['cheap'].bert.fused_qkv_attention = True
+    assert float((one[live] - two[live]).abs().max()) < 2e-3
+    import rag_hip
+    rag_hip.check_faults()
+    w['dense'].close()
+    w['bm25'].close()
