@@ -1,14 +1,14 @@
 #!/bin/bash
 # Counters of one of the 16-bit kernels between the feed-forward blocks (scripts/micro/att16_bench.py --only $1),
 # separate rocprofv3 --pmc passes; $2 = substring of the kernel's name.
-#   scripts/micro/pmc_att16.sh qkv linear384_kernel        scripts/micro/pmc_att16.sh attention attention_kernel
+#   scripts/micro/pmc_att16.sh fused qkv_attention_kernel --pack      scripts/micro/pmc_att16.sh qkv linear384_kernel        scripts/micro/pmc_att16.sh attention attention_kernel
 set -e
-ONLY=$1; KERNEL=$2
+ONLY=$1; KERNEL=$2; EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_$ONLY
 rm -rf $O && mkdir -p $O
-run() { timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/$1 -- python3 $R/scripts/micro/att16_bench.py --only $ONLY --iters 3 > $O/$1.log 2>&1; }
+run() { timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/$1 -- python3 $R/scripts/micro/att16_bench.py --only $ONLY --iters 3 $EXTRA > $O/$1.log 2>&1; }
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES"
